@@ -1,0 +1,198 @@
+/* ukf_batch.h -- C-ABI of the MI355X-native batched UKF engine (libukf_batch.so).
+ *
+ * Drop-in boundary for the ONE hot path of rock-slam/slam-pose_estimation: everything the
+ * reference reaches through its protected member
+ *     boost::shared_ptr<ukfom::ukf<WState> > ukf;          (src/UnscentedKalmanFilter.hpp:150)
+ * i.e. ukf->predict / ukf->update / ukf->mu() / ukf->sigma(), plus the per-filter plumbing around
+ * it (time gate, latched inputs, process-noise shaping), for a BATCH of independent filters that
+ * lives in the HBM of one MI355X.  Host C++ (include/pose_estimation/...hpp) and Python
+ * (slam-pose_estimation_amd/engine.py, ctypes) sit on top of exactly these entry points.
+ *
+ * Conventions
+ *  - plain C, opaque handle, int return codes (UKFB_OK == 0); no exception crosses the ABI.
+ *  - the caller owns host buffers, the engine owns device buffers.
+ *  - calls on one engine must come from one host thread at a time (the reference classes are
+ *    boost::noncopyable and single-threaded, UnscentedKalmanFilter.hpp:16).
+ *  - work is enqueued on the engine's HIP stream; ukfb_sync() waits for it.  Functions that
+ *    copy to host buffers synchronise themselves.
+ *  - host-side numeric arrays are double and AoS ("host layout"):
+ *      Pose   (UKFB_MODEL_POSE,   S=13, D=12): mu = position(3) orientation(x,y,z,w) velocity(3)
+ *              angular_velocity(3)                              (PoseWithVelocity.hpp:18-23)
+ *      Orient (UKFB_MODEL_ORIENT, S=14, D=13): mu = orientation(x,y,z,w) velocity(3) bias_gyro(3)
+ *              bias_acc(3) gravity(1)                            (OrientationState.hpp:20-26)
+ *      cov = D x D row-major (symmetric; the engine stores the lower triangle).
+ *    Quaternion order (x,y,z,w) is Eigen's coefficient order.
+ *  - "_dev" entry points take DEVICE pointers in the engine's compute precision (float or
+ *    double) so that a caller whose inputs are already resident in HBM pays no PCIe copy.
+ *  - per-filter failures never abort a call: they are reported in the per-filter status word
+ *    (UKFB_ST_*), and a failing filter keeps the state it had before the call (the reference
+ *    throws before mutating: UnscentedKalmanFilter.hpp:110-124).
+ */
+#ifndef UKF_BATCH_H
+#define UKF_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ukfb_engine ukfb_engine;
+
+/* ---- return codes ---------------------------------------------------------------------- */
+enum {
+    UKFB_OK = 0,
+    UKFB_ERR_INVALID_ARG = 1,
+    UKFB_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime error at creation               */
+    UKFB_ERR_HIP = 3,         /* HIP runtime error; text via ukfb_last_error()               */
+    UKFB_ERR_OUT_OF_RANGE = 4,
+    UKFB_ERR_WRONG_MODEL = 5  /* e.g. Orient-only call on a Pose engine                      */
+};
+
+/* ---- models / precision ----------------------------------------------------------------- */
+enum { UKFB_MODEL_POSE = 0, UKFB_MODEL_ORIENT = 1 };
+enum { UKFB_F64 = 0, UKFB_F32 = 1 };
+
+/* measurement model ids = the integrateMeasurement overload they replace */
+enum {
+    UKFB_MEAS_NONE = -1,            /* filter takes no measurement in this call              */
+    UKFB_MEAS_POS3 = 0,             /* PoseUKF.cpp:112-117  PositionMeasurement              */
+    UKFB_MEAS_POS_XY = 1,           /* PoseUKF.cpp:119-124  XYMeasurement                    */
+    UKFB_MEAS_POS_Z = 2,            /* PoseUKF.cpp:126-131  ZMeasurement                     */
+    UKFB_MEAS_ORIENT_SO3 = 3,       /* PoseUKF.cpp:133-138  OrientationMeasurement (axis-angle in) */
+    UKFB_MEAS_VEL3 = 4,             /* PoseUKF.cpp:140-145  VelocityMeasurement              */
+    UKFB_MEAS_VEL_XY = 5,           /* PoseUKF.cpp:147-152  XYVelocityMeasurement            */
+    UKFB_MEAS_VEL_Z = 6,            /* PoseUKF.cpp:154-159  ZVelocityMeasurement             */
+    UKFB_MEAS_XVEL_YAWVEL = 7,      /* PoseUKF.cpp:161-166  XVelYawVelMeasurement            */
+    UKFB_MEAS_ANGVEL3 = 8,          /* PoseUKF.cpp:168-173  AngularVelocityMeasurement       */
+    UKFB_MEAS_ORIENT_BODYVEL3 = 9   /* OrientationUKF.cpp:65-72 VelocityMeasurement (Orient)  */
+};
+
+/* ---- per-filter status bits (uint32) ---------------------------------------------------- */
+enum {
+    UKFB_ST_OK = 0u,
+    UKFB_ST_SKIPPED_FIRST_TS = 1u << 0,   /* UnscentedKalmanFilter.hpp:86-90                 */
+    UKFB_ST_SKIPPED_SMALL_DT = 1u << 1,   /* UnscentedKalmanFilter.hpp:114-118               */
+    UKFB_ST_ERR_NEG_DT = 1u << 2,         /* UnscentedKalmanFilter.hpp:110-113 (throws there) */
+    UKFB_ST_ERR_DT_TOO_LARGE = 1u << 3,   /* UnscentedKalmanFilter.hpp:119-122 (throws there) */
+    UKFB_ST_ERR_NONFINITE_MEAS = 1u << 4, /* UnscentedKalmanFilter.hpp:142-147 (throws there) */
+    UKFB_ST_ERR_CHOLESKY = 1u << 5,       /* ukfom: Cholesky decomposition failed            */
+    UKFB_ST_WARN_MEAN_NOCONV = 1u << 6,   /* ukfom: meanSigmaPoints() did not converge       */
+    UKFB_ST_UNINITIALISED = 1u << 7,      /* UnscentedKalmanFilter.hpp:53,59                 */
+    UKFB_ST_INACTIVE = 1u << 8,           /* filter masked out of this call                  */
+    UKFB_ST_REJECTED_GATE = 1u << 9       /* mahalanobis gate rejected the update            */
+};
+
+/* ---- configuration ---------------------------------------------------------------------- */
+typedef struct ukfb_config {
+    double mean_tol;        /* ukfom meanSigmaPoints tolerance (1e-6)                        */
+    int32_t mean_max_iter;  /* ukfom meanSigmaPoints cap (engine default 100, ukfom 10000)   */
+    double gate_chi2;       /* < 0: accept_any_mahalanobis_distance (PoseUKF.cpp:116)        */
+    double min_time_delta;  /* UnscentedKalmanFilter.hpp:31  (1e-9)                          */
+    double max_time_delta;  /* UnscentedKalmanFilter.hpp:32  (DBL_MAX)                       */
+    int32_t lanes_per_filter; /* 16, 32 or 64 lanes of a wavefront per filter; 0 = default   */
+} ukfb_config;
+
+int ukfb_default_config(ukfb_config* cfg);
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* Replaces `new MTK_UKF(initial_state, state_cov)` per filter (UnscentedKalmanFilter.hpp:42)
+ * by one engine holding `capacity` filters on HIP device `device`.  `stream` is a hipStream_t
+ * (NULL: the engine creates its own non-blocking stream). */
+int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream);
+int ukfb_destroy(ukfb_engine* e);
+const char* ukfb_last_error(void);
+int ukfb_set_config(ukfb_engine* e, const ukfb_config* cfg);
+int ukfb_get_config(const ukfb_engine* e, ukfb_config* cfg);
+int ukfb_sync(ukfb_engine* e);
+
+/* introspection: model, precision, capacity, S (stored scalars), D (DOF), packed cov length */
+int ukfb_describe(const ukfb_engine* e, int* model, int* precision, int64_t* capacity, int* S, int* D, int* PK);
+
+/* ---- state (UnscentedKalmanFilter.hpp:40-75) -------------------------------------------- */
+/* initializeFilter(state, cov) for filters [first, first+count): sets mu, cov, marks the filter
+ * initialised and zeroes its last_measurement_time (:40-44). */
+int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* mu, const double* cov);
+/* getCurrentState (:51-75): mu and/or cov may be NULL; initialised (uint8 per filter, may be
+ * NULL) is the function's bool return. */
+int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised);
+/* per-filter status words of the most recent predict / update / cycle call */
+int ukfb_get_status(ukfb_engine* e, int64_t first, int64_t count, uint32_t* status);
+/* OR of all status words of the most recent call (cheap health check) */
+int ukfb_get_status_summary(ukfb_engine* e, uint32_t* or_of_all);
+
+/* get/setLastMeasurementTime (:131-133), int64 microseconds as base::Time */
+int ukfb_set_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count, const int64_t* t_us);
+int ukfb_get_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count, int64_t* t_us);
+
+/* raw device views (engine precision): mu [capacity][S], packed lower-triangular cov
+ * [capacity][PK] (row-major: index r(r+1)/2 + c, c <= r), status [capacity]. */
+int ukfb_device_views(ukfb_engine* e, void** mu_dev, void** cov_packed_dev, uint32_t** status_dev);
+
+/* ---- process noise / latched inputs ------------------------------------------------------ */
+/* setProcessNoiseCovariance (:130): one D x D matrix for the whole batch ... */
+int ukfb_set_process_noise(ukfb_engine* e, const double* R);
+/* ... or one per filter ([count][D][D]); the first per-filter call switches the engine to
+ * per-filter storage (initialised from the batch-uniform matrix). */
+int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t count, const double* R);
+int ukfb_get_process_noise(ukfb_engine* e, int64_t filter, double* R);
+
+/* PoseUKF::integrateMeasurement(AccelerationMeasurement) (PoseUKF.cpp:175-178): latch acc.mu per
+ * filter ([count][3]; a NaN row = "no acceleration", the ctor default PoseUKF.cpp:109) and the
+ * batch-uniform acc.cov (3x3; NULL keeps the current one, default Identity, Measurement.hpp:12). */
+int ukfb_pose_set_acceleration(ukfb_engine* e, int64_t first, int64_t count, const double* acc_mu,
+                               const double* acc_cov);
+/* device-resident variant: acc_mu_dev [capacity][3] in engine precision, used directly (no copy)
+ * by later predict/cycle calls until replaced; NULL returns to the engine-owned buffer. */
+int ukfb_pose_bind_acceleration_dev(ukfb_engine* e, const void* acc_mu_dev);
+
+/* OrientationUKF ctor parameters (OrientationUKF.cpp:41-51): taus and earth rotation vector. */
+int ukfb_orient_set_params(ukfb_engine* e, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3]);
+/* OrientationUKF::integrateMeasurement(RotationRate / Acceleration) (:53-63): latch per filter;
+ * either pointer may be NULL to leave that input unchanged.  Non-finite rows are rejected
+ * per filter (status ERR_NONFINITE_MEAS, previous value kept) as checkMeasurment does (:55,61). */
+int ukfb_orient_set_inputs(ukfb_engine* e, int64_t first, int64_t count, const double* gyro, const double* acc);
+int ukfb_orient_bind_inputs_dev(ukfb_engine* e, const void* gyro_dev, const void* acc_dev);
+/* OrientationUKF::getRotationRate (:74-77) for filters [first, first+count): out [count][3] */
+int ukfb_orient_get_rotation_rate(ukfb_engine* e, int64_t first, int64_t count, double* out);
+
+/* ---- predict (UnscentedKalmanFilter.hpp:83-125 + predictionStepImpl) --------------------- */
+/* predictionStep(delta_t) with one dt for every filter */
+int ukfb_predict(ukfb_engine* e, double dt);
+/* predictionStep(delta_t[i]) (host array [capacity]) */
+int ukfb_predict_dt(ukfb_engine* e, const double* dt);
+/* predictionStepFromSampleTime(ts[i]) (host array [capacity], int64 microseconds) */
+int ukfb_predict_timestamps(ukfb_engine* e, const int64_t* ts_us);
+/* device-resident variants (double / int64 device arrays [capacity]) */
+int ukfb_predict_dt_dev(ukfb_engine* e, const double* dt_dev);
+int ukfb_predict_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev);
+
+/* ---- update (integrateMeasurement -> ukf->update) ---------------------------------------- */
+/* One model id for the batch.  z [capacity][3] (first m entries used; axis-angle for ORIENT_SO3),
+ * Q [capacity][3][3] (leading m x m block used), active (uint8 [capacity], may be NULL = all). */
+int ukfb_update(ukfb_engine* e, int meas_model, const double* z, const double* Q, const uint8_t* active);
+/* per-filter model ids (int32 [capacity]; negative = no measurement for that filter) */
+int ukfb_update_mixed(ukfb_engine* e, const int32_t* meas_model, const double* z, const double* Q);
+/* device-resident variants: z_dev [capacity][3], Q_dev [capacity][9] in engine precision;
+ * meas_model_dev int32 [capacity] or NULL (then meas_model_uniform applies to every filter). */
+int ukfb_update_dev(ukfb_engine* e, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
+                    const void* Q_dev);
+
+/* ---- fused cycle: predictionStep(dt) followed by integrateMeasurement, one launch -------- */
+int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q);
+int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
+                   const void* Q_dev);
+
+/* ---- measurement of the engine itself ---------------------------------------------------- */
+/* name, dynamic LDS bytes per workgroup, filters per workgroup and grid size of the kernel the
+ * most recent predict/update/cycle call launched (for profiles/ and bench.py) */
+int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capacity, int* lds_bytes,
+                          int* filters_per_workgroup, int64_t* grid);
+/* HIP-event timing on the engine's stream: begin/end bracket a region, elapsed in ms */
+int ukfb_timer_begin(ukfb_engine* e);
+int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UKF_BATCH_H */

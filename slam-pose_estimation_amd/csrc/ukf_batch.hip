@@ -1,0 +1,630 @@
+// ukf_batch.hip -- implementation of the C-ABI declared in include/ukf_batch.h.
+//
+// Host-side plumbing only: device allocation, AoS(double, full covariance) <-> device (engine
+// precision, packed lower triangle) conversion, latched inputs, launch requests.  All arithmetic
+// of the hot path is in ukf_kernel.hpp.  There is deliberately NO CPU fallback: without a HIP
+// device ukfb_create fails with UKFB_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "ukf_engine.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            ukfb::set_error(#expr, _e);                    \
+            return UKFB_ERR_HIP;                           \
+        }                                                  \
+    } while (0)
+
+bool range_ok(const ukfb_engine* e, int64_t first, int64_t count) {
+    return e && first >= 0 && count >= 0 && first + count <= e->cap;
+}
+
+int fail(int code, const char* msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// pack / convert host doubles into engine precision -------------------------------------------
+template <class T> void convert(const double* src, T* dst, size_t n) {
+    for (size_t i = 0; i < n; ++i) dst[i] = T(src[i]);
+}
+
+int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src, size_t n) {
+    if (n == 0) return UKFB_OK;
+    if (e->prec == UKFB_F64) {
+        HIP_TRY(hipMemcpyAsync(static_cast<double*>(dst_dev) + elem_offset, src, n * sizeof(double),
+                               hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    } else {
+        std::vector<float> tmp(n);
+        convert(src, tmp.data(), n);
+        HIP_TRY(hipMemcpyAsync(static_cast<float*>(dst_dev) + elem_offset, tmp.data(), n * sizeof(float),
+                               hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return UKFB_OK;
+}
+
+int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* dst, size_t n) {
+    if (n == 0) return UKFB_OK;
+    if (e->prec == UKFB_F64) {
+        HIP_TRY(hipMemcpyAsync(dst, static_cast<const double*>(src_dev) + elem_offset, n * sizeof(double),
+                               hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    } else {
+        std::vector<float> tmp(n);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), static_cast<const float*>(src_dev) + elem_offset, n * sizeof(float),
+                               hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < n; ++i) dst[i] = double(tmp[i]);
+    }
+    return UKFB_OK;
+}
+
+template <class P> int upload_raw(ukfb_engine* e, P* dst_dev, const P* src, size_t n) {
+    if (n == 0) return UKFB_OK;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src, n * sizeof(P), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return UKFB_OK;
+}
+
+template <class P> int download_raw(ukfb_engine* e, const P* src_dev, P* dst, size_t n) {
+    if (n == 0) return UKFB_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, n * sizeof(P), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return UKFB_OK;
+}
+
+int fill_scalar(ukfb_engine* e, void* dst_dev, size_t n, double value) {
+    std::vector<double> v(n, value);
+    return upload(e, dst_dev, 0, v.data(), n);
+}
+
+int launch(ukfb_engine* e, const ukfb::LaunchReq& r) {
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->model == UKFB_MODEL_POSE)
+        return e->prec == UKFB_F64 ? ukfb::launch_pose_f64(e, r) : ukfb::launch_pose_f32(e, r);
+    return e->prec == UKFB_F64 ? ukfb::launch_orient_f64(e, r) : ukfb::launch_orient_f32(e, r);
+}
+
+bool meas_model_ok(const ukfb_engine* e, int m) {
+    if (e->model == UKFB_MODEL_POSE) return m >= UKFB_MEAS_POS3 && m <= UKFB_MEAS_ANGVEL3;
+    return m == UKFB_MEAS_ORIENT_BODYVEL3;
+}
+
+// stage host measurement arrays into the engine's device buffers
+int stage_measurements(ukfb_engine* e, const double* z, const double* Q, const int32_t* meas, const uint8_t* active) {
+    if (!z || !Q) return fail(UKFB_ERR_INVALID_ARG, "z and Q must not be NULL");
+    int rc = upload(e, e->z_stage, 0, z, size_t(e->cap) * 3);
+    if (rc) return rc;
+    rc = upload(e, e->Q_stage, 0, Q, size_t(e->cap) * 9);
+    if (rc) return rc;
+    if (meas) {
+        rc = upload_raw(e, e->meas_stage, meas, size_t(e->cap));
+        if (rc) return rc;
+    }
+    if (active) {
+        rc = upload_raw(e, e->active_stage, active, size_t(e->cap));
+        if (rc) return rc;
+    }
+    return UKFB_OK;
+}
+
+__global__ void or_reduce_kernel(const uint32_t* st, int64_t n, uint32_t* out) {
+    uint32_t v = 0;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        v |= st[i];
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(out, v);
+}
+
+}  // namespace
+
+namespace ukfb {
+void set_error(const char* what, hipError_t err) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(err);
+}
+}  // namespace ukfb
+
+extern "C" {
+
+const char* ukfb_last_error(void) { return g_last_error.c_str(); }
+
+int ukfb_default_config(ukfb_config* cfg) {
+    if (!cfg) return UKFB_ERR_INVALID_ARG;
+    cfg->mean_tol = 1e-6;
+    cfg->mean_max_iter = 100;
+    cfg->gate_chi2 = -1.0;
+    cfg->min_time_delta = 1.0e-9;
+    cfg->max_time_delta = std::numeric_limits<double>::max();
+    cfg->lanes_per_filter = 16;
+    return UKFB_OK;
+}
+
+int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream) {
+    if (!out || capacity <= 0 || (model != UKFB_MODEL_POSE && model != UKFB_MODEL_ORIENT) ||
+        (precision != UKFB_F64 && precision != UKFB_F32))
+        return fail(UKFB_ERR_INVALID_ARG, "ukfb_create: bad argument");
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_last_error = "ukfb_create: no usable HIP device (the engine has no CPU fallback)";
+        return UKFB_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    ukfb_engine* e = new (std::nothrow) ukfb_engine();
+    if (!e) return fail(UKFB_ERR_INVALID_ARG, "out of host memory");
+    e->model = model;
+    e->prec = precision;
+    e->cap = capacity;
+    e->device = device;
+    e->S = model == UKFB_MODEL_POSE ? 13 : 14;
+    e->D = model == UKFB_MODEL_POSE ? 12 : 13;
+    e->PK = e->D * (e->D + 1) / 2;
+    e->tsize = precision == UKFB_F64 ? 8 : 4;
+    ukfb_default_config(&e->cfg);
+    if (stream) {
+        e->stream = static_cast<hipStream_t>(stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    const size_t n = size_t(capacity), ts = e->tsize;
+    HIP_TRY(hipMalloc(&e->mu, n * e->S * ts));
+    HIP_TRY(hipMalloc(&e->cov, n * e->PK * ts));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->status), n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->init), n));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->last_ts), n * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&e->Rn, size_t(e->D) * e->D * ts));
+    HIP_TRY(hipMalloc(&e->in_a, n * 3 * ts));
+    HIP_TRY(hipMalloc(&e->in_b, n * 3 * ts));
+    HIP_TRY(hipMalloc(&e->z_stage, n * 3 * ts));
+    HIP_TRY(hipMalloc(&e->Q_stage, n * 9 * ts));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->meas_stage), n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->active_stage), n));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->dt_stage), n * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ts_stage), n * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->reduce_word), sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(e->mu, 0, n * e->S * ts, e->stream));
+    HIP_TRY(hipMemsetAsync(e->cov, 0, n * e->PK * ts, e->stream));
+    HIP_TRY(hipMemsetAsync(e->status, 0, n * sizeof(uint32_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->init, 0, n, e->stream));
+    HIP_TRY(hipMemsetAsync(e->last_ts, 0, n * sizeof(int64_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Rn, 0, size_t(e->D) * e->D * ts, e->stream));  // UnscentedKalmanFilter.hpp:29
+    HIP_TRY(hipMemsetAsync(e->in_b, 0, n * 3 * ts, e->stream));
+    HIP_TRY(hipMemsetAsync(e->z_stage, 0, n * 3 * ts, e->stream));
+    HIP_TRY(hipMemsetAsync(e->Q_stage, 0, n * 9 * ts, e->stream));
+    e->Rn_host.assign(size_t(e->D) * e->D, 0.0);
+    int rc;
+    if (model == UKFB_MODEL_POSE)  // acceleration.mu = NaN until set (PoseUKF.cpp:109)
+        rc = fill_scalar(e, e->in_a, n * 3, std::numeric_limits<double>::quiet_NaN());
+    else
+        rc = fill_scalar(e, e->in_a, n * 3, 0.0);
+    if (rc) return rc;
+    HIP_TRY(hipEventCreate(&e->ev0));
+    HIP_TRY(hipEventCreate(&e->ev1));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *out = e;
+    return UKFB_OK;
+}
+
+int ukfb_destroy(ukfb_engine* e) {
+    if (!e) return UKFB_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->in_a, e->in_b, e->z_stage, e->Q_stage,
+                    e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return UKFB_OK;
+}
+
+int ukfb_set_config(ukfb_engine* e, const ukfb_config* cfg) {
+    if (!e || !cfg) return UKFB_ERR_INVALID_ARG;
+    ukfb_config c = *cfg;
+    if (c.lanes_per_filter == 0) c.lanes_per_filter = 16;
+    if (c.lanes_per_filter != 16 && c.lanes_per_filter != 32 && c.lanes_per_filter != 64)
+        return fail(UKFB_ERR_INVALID_ARG, "lanes_per_filter must be 16, 32 or 64");
+    if (c.mean_max_iter < 1) return fail(UKFB_ERR_INVALID_ARG, "mean_max_iter must be >= 1");
+    e->cfg = c;
+    return UKFB_OK;
+}
+
+int ukfb_get_config(const ukfb_engine* e, ukfb_config* cfg) {
+    if (!e || !cfg) return UKFB_ERR_INVALID_ARG;
+    *cfg = e->cfg;
+    return UKFB_OK;
+}
+
+int ukfb_sync(ukfb_engine* e) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return UKFB_OK;
+}
+
+int ukfb_describe(const ukfb_engine* e, int* model, int* precision, int64_t* capacity, int* S, int* D, int* PK) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (model) *model = e->model;
+    if (precision) *precision = e->prec;
+    if (capacity) *capacity = e->cap;
+    if (S) *S = e->S;
+    if (D) *D = e->D;
+    if (PK) *PK = e->PK;
+    return UKFB_OK;
+}
+
+int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* mu, const double* cov) {
+    if (!range_ok(e, first, count) || !mu || !cov) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_initialize: bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    const int D = e->D, PK = e->PK;
+    std::vector<double> packed(size_t(count) * PK);
+    for (int64_t i = 0; i < count; ++i) {
+        const double* c = cov + size_t(i) * D * D;
+        double* p = packed.data() + size_t(i) * PK;
+        for (int r = 0; r < D; ++r)
+            for (int k = 0; k <= r; ++k) p[r * (r + 1) / 2 + k] = c[r * D + k];
+    }
+    int rc = upload(e, e->mu, size_t(first) * e->S, mu, size_t(count) * e->S);
+    if (rc) return rc;
+    rc = upload(e, e->cov, size_t(first) * PK, packed.data(), size_t(count) * PK);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
+    HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return UKFB_OK;
+}
+
+int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised) {
+    if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_get_state: bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    const int D = e->D, PK = e->PK;
+    int rc;
+    if (mu) {
+        rc = download(e, e->mu, size_t(first) * e->S, mu, size_t(count) * e->S);
+        if (rc) return rc;
+    }
+    if (cov) {
+        std::vector<double> packed(size_t(count) * PK);
+        rc = download(e, e->cov, size_t(first) * PK, packed.data(), size_t(count) * PK);
+        if (rc) return rc;
+        for (int64_t i = 0; i < count; ++i) {
+            double* c = cov + size_t(i) * D * D;
+            const double* p = packed.data() + size_t(i) * PK;
+            for (int r = 0; r < D; ++r)
+                for (int k = 0; k <= r; ++k) c[r * D + k] = c[k * D + r] = p[r * (r + 1) / 2 + k];
+        }
+    }
+    if (initialised) {
+        rc = download_raw(e, e->init + first, initialised, size_t(count));
+        if (rc) return rc;
+    }
+    return UKFB_OK;
+}
+
+int ukfb_get_status(ukfb_engine* e, int64_t first, int64_t count, uint32_t* status) {
+    if (!range_ok(e, first, count) || !status) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_get_status: bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    return download_raw(e, e->status + first, status, size_t(count));
+}
+
+int ukfb_get_status_summary(ukfb_engine* e, uint32_t* or_of_all) {
+    if (!e || !or_of_all) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->reduce_word, 0, sizeof(uint32_t), e->stream));
+    const int blocks = int(std::min<int64_t>((e->cap + 255) / 256, 1024));
+    hipLaunchKernelGGL(or_reduce_kernel, dim3(blocks), dim3(256), 0, e->stream, e->status, e->cap, e->reduce_word);
+    return download_raw(e, e->reduce_word, or_of_all, 1);
+}
+
+int ukfb_set_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count, const int64_t* t_us) {
+    if (!range_ok(e, first, count) || !t_us) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    return upload_raw(e, e->last_ts + first, t_us, size_t(count));
+}
+
+int ukfb_get_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count, int64_t* t_us) {
+    if (!range_ok(e, first, count) || !t_us) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    return download_raw(e, e->last_ts + first, t_us, size_t(count));
+}
+
+int ukfb_device_views(ukfb_engine* e, void** mu_dev, void** cov_packed_dev, uint32_t** status_dev) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (mu_dev) *mu_dev = e->mu;
+    if (cov_packed_dev) *cov_packed_dev = e->cov;
+    if (status_dev) *status_dev = e->status;
+    return UKFB_OK;
+}
+
+int ukfb_set_process_noise(ukfb_engine* e, const double* R) {
+    if (!e || !R) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t dd = size_t(e->D) * e->D;
+    e->Rn_host.assign(R, R + dd);
+    if (e->Rn_per_filter) {
+        std::vector<double> all(size_t(e->cap) * dd);
+        for (int64_t i = 0; i < e->cap; ++i) std::memcpy(all.data() + size_t(i) * dd, R, dd * sizeof(double));
+        return upload(e, e->Rn, 0, all.data(), all.size());
+    }
+    return upload(e, e->Rn, 0, R, dd);
+}
+
+int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t count, const double* R) {
+    if (!range_ok(e, first, count) || !R) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t dd = size_t(e->D) * e->D;
+    if (!e->Rn_per_filter) {
+        void* big = nullptr;
+        HIP_TRY(hipMalloc(&big, size_t(e->cap) * dd * e->tsize));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(e->Rn));
+        e->Rn = big;
+        e->Rn_per_filter = true;
+        std::vector<double> all(size_t(e->cap) * dd);
+        for (int64_t i = 0; i < e->cap; ++i)
+            std::memcpy(all.data() + size_t(i) * dd, e->Rn_host.data(), dd * sizeof(double));
+        int rc = upload(e, e->Rn, 0, all.data(), all.size());
+        if (rc) return rc;
+    }
+    return upload(e, e->Rn, size_t(first) * dd, R, size_t(count) * dd);
+}
+
+int ukfb_get_process_noise(ukfb_engine* e, int64_t filter, double* R) {
+    if (!range_ok(e, filter, 1) || !R) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t dd = size_t(e->D) * e->D;
+    return download(e, e->Rn, e->Rn_per_filter ? size_t(filter) * dd : 0, R, dd);
+}
+
+int ukfb_pose_set_acceleration(ukfb_engine* e, int64_t first, int64_t count, const double* acc_mu,
+                               const double* acc_cov) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
+    if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    if (acc_cov) std::memcpy(e->acc_cov, acc_cov, 9 * sizeof(double));
+    if (acc_mu) return upload(e, e->in_a, size_t(first) * 3, acc_mu, size_t(count) * 3);
+    return UKFB_OK;
+}
+
+int ukfb_pose_bind_acceleration_dev(ukfb_engine* e, const void* acc_mu_dev) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
+    e->in_a_bound = acc_mu_dev;
+    return UKFB_OK;
+}
+
+int ukfb_orient_set_params(ukfb_engine* e, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3]) {
+    if (!e || !earth_rotation) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_ORIENT) return fail(UKFB_ERR_WRONG_MODEL, "Orient engines only");
+    e->tau_g = gyro_bias_tau;
+    e->tau_a = acc_bias_tau;
+    for (int k = 0; k < 3; ++k) e->earth[k] = earth_rotation[k];
+    return UKFB_OK;
+}
+
+int ukfb_orient_set_inputs(ukfb_engine* e, int64_t first, int64_t count, const double* gyro, const double* acc) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_ORIENT) return fail(UKFB_ERR_WRONG_MODEL, "Orient engines only");
+    if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    // checkMeasurment (OrientationUKF.cpp:55,61): a non-finite row keeps the previously latched value
+    auto latch = [&](void* dev, const double* src) -> int {
+        bool all_finite = true;
+        for (int64_t i = 0; i < count * 3 && all_finite; ++i) all_finite = std::isfinite(src[i]);
+        if (all_finite) return upload(e, dev, size_t(first) * 3, src, size_t(count) * 3);
+        std::vector<double> cur(static_cast<size_t>(count) * 3, 0.0);
+        int rc = download(e, dev, size_t(first) * 3, cur.data(), cur.size());
+        if (rc) return rc;
+        std::vector<uint32_t> st(static_cast<size_t>(count), 0u);
+        rc = download_raw(e, e->status + first, st.data(), st.size());
+        if (rc) return rc;
+        for (int64_t i = 0; i < count; ++i) {
+            const double* r = src + i * 3;
+            if (std::isfinite(r[0]) && std::isfinite(r[1]) && std::isfinite(r[2]))
+                std::memcpy(cur.data() + i * 3, r, 3 * sizeof(double));
+            else
+                st[size_t(i)] |= UKFB_ST_ERR_NONFINITE_MEAS;
+        }
+        rc = upload(e, dev, size_t(first) * 3, cur.data(), cur.size());
+        if (rc) return rc;
+        return upload_raw(e, e->status + first, st.data(), st.size());
+    };
+    int rc = UKFB_OK;
+    if (gyro) rc = latch(e->in_b, gyro);
+    if (rc) return rc;
+    if (acc) rc = latch(e->in_a, acc);
+    return rc;
+}
+
+int ukfb_orient_bind_inputs_dev(ukfb_engine* e, const void* gyro_dev, const void* acc_dev) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_ORIENT) return fail(UKFB_ERR_WRONG_MODEL, "Orient engines only");
+    e->in_b_bound = gyro_dev;
+    e->in_a_bound = acc_dev;
+    return UKFB_OK;
+}
+
+int ukfb_orient_get_rotation_rate(ukfb_engine* e, int64_t first, int64_t count, double* out) {
+    if (!e || !out) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_ORIENT) return fail(UKFB_ERR_WRONG_MODEL, "Orient engines only");
+    if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    HIP_TRY(hipSetDevice(e->device));
+    // rotation_rate.mu - bias_gyro - q^-1 * earth_rotation (OrientationUKF.cpp:74-77): a read-out of
+    // latched input and mean, not part of the predict/update arithmetic, evaluated host-side.
+    std::vector<double> mu(size_t(count) * 14), w(size_t(count) * 3);
+    int rc = download(e, e->mu, size_t(first) * 14, mu.data(), mu.size());
+    if (rc) return rc;
+    const void* gy = e->in_b_bound ? e->in_b_bound : e->in_b;
+    rc = download(e, gy, size_t(first) * 3, w.data(), w.size());
+    if (rc) return rc;
+    for (int64_t i = 0; i < count; ++i) {
+        const double* m = mu.data() + i * 14;
+        const double n2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3];
+        const double q[4] = {-m[0] / n2, -m[1] / n2, -m[2] / n2, m[3] / n2};
+        const double* v = e->earth;
+        double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+        ux += ux; uy += uy; uz += uz;
+        const double r0 = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+        const double r1 = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+        const double r2 = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+        out[i * 3 + 0] = w[size_t(i) * 3 + 0] - m[7] - r0;
+        out[i * 3 + 1] = w[size_t(i) * 3 + 1] - m[8] - r1;
+        out[i * 3 + 2] = w[size_t(i) * 3 + 2] - m[9] - r2;
+    }
+    return UKFB_OK;
+}
+
+// ---- predict ------------------------------------------------------------------------------------
+int ukfb_predict(ukfb_engine* e, double dt) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.dt_uniform = dt;
+    return launch(e, r);
+}
+
+int ukfb_predict_dt_dev(ukfb_engine* e, const double* dt_dev) {
+    if (!e || !dt_dev) return UKFB_ERR_INVALID_ARG;
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.dt_dev = dt_dev;
+    return launch(e, r);
+}
+
+int ukfb_predict_dt(ukfb_engine* e, const double* dt) {
+    if (!e || !dt) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = upload_raw(e, e->dt_stage, dt, size_t(e->cap));
+    if (rc) return rc;
+    return ukfb_predict_dt_dev(e, e->dt_stage);
+}
+
+int ukfb_predict_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev) {
+    if (!e || !ts_us_dev) return UKFB_ERR_INVALID_ARG;
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.ts_dev = ts_us_dev;
+    return launch(e, r);
+}
+
+int ukfb_predict_timestamps(ukfb_engine* e, const int64_t* ts_us) {
+    if (!e || !ts_us) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = upload_raw(e, e->ts_stage, ts_us, size_t(e->cap));
+    if (rc) return rc;
+    return ukfb_predict_timestamps_dev(e, e->ts_stage);
+}
+
+// ---- update -------------------------------------------------------------------------------------
+int ukfb_update_dev(ukfb_engine* e, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
+                    const void* Q_dev) {
+    if (!e || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_dev && !meas_model_ok(e, meas_model_uniform))
+        return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    ukfb::LaunchReq r;
+    r.do_update = true;
+    r.meas_uniform = meas_model_uniform;
+    r.meas_dev = meas_model_dev;
+    r.z_dev = z_dev;
+    r.Q_dev = Q_dev;
+    return launch(e, r);
+}
+
+int ukfb_update(ukfb_engine* e, int meas_model, const double* z, const double* Q, const uint8_t* active) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = stage_measurements(e, z, Q, nullptr, active);
+    if (rc) return rc;
+    ukfb::LaunchReq r;
+    r.do_update = true;
+    r.meas_uniform = meas_model;
+    r.z_dev = e->z_stage;
+    r.Q_dev = e->Q_stage;
+    r.active_dev = active ? e->active_stage : nullptr;
+    return launch(e, r);
+}
+
+int ukfb_update_mixed(ukfb_engine* e, const int32_t* meas_model, const double* z, const double* Q) {
+    if (!e || !meas_model) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = stage_measurements(e, z, Q, meas_model, nullptr);
+    if (rc) return rc;
+    ukfb::LaunchReq r;
+    r.do_update = true;
+    r.meas_dev = e->meas_stage;
+    r.z_dev = e->z_stage;
+    r.Q_dev = e->Q_stage;
+    return launch(e, r);
+}
+
+// ---- fused cycle --------------------------------------------------------------------------------
+int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
+                   const void* Q_dev) {
+    if (!e || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_dev && !meas_model_ok(e, meas_model_uniform))
+        return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.do_update = true;
+    r.dt_uniform = dt;
+    r.meas_uniform = meas_model_uniform;
+    r.meas_dev = meas_model_dev;
+    r.z_dev = z_dev;
+    r.Q_dev = Q_dev;
+    return launch(e, r);
+}
+
+int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = stage_measurements(e, z, Q, nullptr, nullptr);
+    if (rc) return rc;
+    return ukfb_cycle_dev(e, dt, meas_model, nullptr, e->z_stage, e->Q_stage);
+}
+
+// ---- measurement of the engine ------------------------------------------------------------------
+int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capacity, int* lds_bytes,
+                          int* filters_per_workgroup, int64_t* grid) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    if (kernel_name && name_capacity > 0) {
+        std::snprintf(kernel_name, size_t(name_capacity), "%s", e->last_kernel.c_str());
+    }
+    if (lds_bytes) *lds_bytes = e->last_lds;
+    if (filters_per_workgroup) *filters_per_workgroup = e->last_fpw;
+    if (grid) *grid = e->last_grid;
+    return UKFB_OK;
+}
+
+int ukfb_timer_begin(ukfb_engine* e) {
+    if (!e) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    return UKFB_OK;
+}
+
+int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms) {
+    if (!e || !elapsed_ms) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
+    return UKFB_OK;
+}
+
+}  // extern "C"

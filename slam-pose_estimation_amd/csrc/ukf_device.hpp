@@ -1,0 +1,282 @@
+// ukf_device.hpp -- gfx950 device-side math for the batched UKF engine.
+//
+// SO(3) exp/log, quaternion algebra, compound-manifold boxplus/boxminus and the process /
+// measurement models, written for register-resident fixed-size arrays (every loop is fully
+// unrolled so that no array is indexed at run time and nothing spills to scratch).
+//
+// Behaviour follows the reference call sites (paths relative to /root/reference/src):
+//   pose_with_velocity/PoseUKF.cpp:75-97        processModel / processModelWithAcceleration
+//   pose_with_velocity/PoseUKF.cpp:7-69         measurement models
+//   orientation_estimator/OrientationUKF.cpp:12-39   processModel / velocityMeasurementModel
+// and the MTK semantics recalled in SURVEY.md Appendix A (SO3::exp/log with the
+// cos_sinc_sqrt Taylor switch, right-multiplying boxplus, atan-based log).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UKFB_DEV __device__ __forceinline__
+
+namespace ukfb {
+
+template <class T> struct Num;
+template <> struct Num<double> {
+    // sqrt(sqrt(DBL_EPSILON)) = 2^-13
+    static constexpr double taylor_n_bound = 0.0001220703125;
+    static constexpr double mtk_tol = 1e-11;
+};
+template <> struct Num<float> {
+    // sqrt(sqrt(FLT_EPSILON)) = 2^-5.75
+    static constexpr float taylor_n_bound = 0.018581361f;
+    static constexpr float mtk_tol = 1e-5f;
+};
+
+UKFB_DEV double m_sqrt(double x) { return sqrt(x); }
+UKFB_DEV float m_sqrt(float x) { return sqrtf(x); }
+UKFB_DEV double m_atan(double x) { return atan(x); }
+UKFB_DEV float m_atan(float x) { return atanf(x); }
+UKFB_DEV void m_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+UKFB_DEV void m_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+UKFB_DEV bool m_finite(double x) { return isfinite(x); }
+UKFB_DEV bool m_finite(float x) { return isfinite(x); }
+
+enum { QX = 0, QY = 1, QZ = 2, QW = 3 };
+
+// MTK cos_sinc_sqrt: (cos(sqrt(x2)), sin(sqrt(x2))/sqrt(x2)), three Taylor pairs below eps^(1/4).
+template <class T> UKFB_DEV void cos_sinc_sqrt(T x2, T& c, T& s) {
+    T cosi = T(1), sinc = T(1);
+    T term = T(-0.5) * x2;
+    cosi += term; term *= T(1 / 3.); sinc += term; term *= T(-1 / 4.) * x2;
+    cosi += term; term *= T(1 / 5.); sinc += term; term *= T(-1 / 6.) * x2;
+    cosi += term; term *= T(1 / 7.); sinc += term;
+    if (x2 >= Num<T>::taylor_n_bound) {
+        const T x = m_sqrt(x2);
+        T sn, cs;
+        m_sincos(x, &sn, &cs);
+        cosi = cs;
+        sinc = sn / x;
+    }
+    c = cosi;
+    s = sinc;
+}
+
+template <class T> UKFB_DEV void quat_mul(const T (&a)[4], const T (&b)[4], T (&r)[4]) {
+    const T w = a[QW] * b[QW] - a[QX] * b[QX] - a[QY] * b[QY] - a[QZ] * b[QZ];
+    const T x = a[QW] * b[QX] + a[QX] * b[QW] + a[QY] * b[QZ] - a[QZ] * b[QY];
+    const T y = a[QW] * b[QY] + a[QY] * b[QW] + a[QZ] * b[QX] - a[QX] * b[QZ];
+    const T z = a[QW] * b[QZ] + a[QZ] * b[QW] + a[QX] * b[QY] - a[QY] * b[QX];
+    r[QX] = x; r[QY] = y; r[QZ] = z; r[QW] = w;
+}
+
+// Eigen _transformVector: v + w*uv + vec x uv, uv = 2 (vec x v)
+template <class T> UKFB_DEV void quat_rotate(const T (&q)[4], const T (&v)[3], T (&r)[3]) {
+    T ux = q[QY] * v[2] - q[QZ] * v[1];
+    T uy = q[QZ] * v[0] - q[QX] * v[2];
+    T uz = q[QX] * v[1] - q[QY] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    const T cx = q[QY] * uz - q[QZ] * uy;
+    const T cy = q[QZ] * ux - q[QX] * uz;
+    const T cz = q[QX] * uy - q[QY] * ux;
+    const T r0 = v[0] + q[QW] * ux + cx;
+    const T r1 = v[1] + q[QW] * uy + cy;
+    const T r2 = v[2] + q[QW] * uz + cz;
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+
+// Eigen toRotationMatrix, row-major
+template <class T> UKFB_DEV void quat_to_matrix(const T (&q)[4], T (&R)[9]) {
+    const T tx = T(2) * q[QX], ty = T(2) * q[QY], tz = T(2) * q[QZ];
+    const T twx = tx * q[QW], twy = ty * q[QW], twz = tz * q[QW];
+    const T txx = tx * q[QX], txy = ty * q[QX], txz = tz * q[QX];
+    const T tyy = ty * q[QY], tyz = tz * q[QY], tzz = tz * q[QZ];
+    R[0] = T(1) - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+    R[3] = txy + twz;          R[4] = T(1) - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = T(1) - (txx + tyy);
+}
+
+// MTK SO3::exp(v, scale)
+template <class T> UKFB_DEV void so3_exp(const T (&v)[3], T scale, T (&q)[4]) {
+    const T s = scale * T(0.5);
+    const T n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    T c, sc;
+    cos_sinc_sqrt(s * s * n2, c, sc);
+    const T mult = sc * s;
+    q[QX] = mult * v[0]; q[QY] = mult * v[1]; q[QZ] = mult * v[2]; q[QW] = c;
+}
+
+// MTK SO3::log(q): 2 atan(|vec| / w) / |vec| * vec  (plus/minus periodic)
+template <class T> UKFB_DEV void so3_log(const T (&q)[4], T (&r)[3]) {
+    T nv = m_sqrt(q[QX] * q[QX] + q[QY] * q[QY] + q[QZ] * q[QZ]);
+    nv = nv < Num<T>::mtk_tol ? Num<T>::mtk_tol : nv;
+    const T s = T(2) / nv * m_atan(nv / q[QW]);
+    r[0] = s * q[QX]; r[1] = s * q[QY]; r[2] = s * q[QZ];
+}
+
+// q <- q * exp(v, scale)
+template <class T> UKFB_DEV void so3_boxplus(T (&q)[4], const T (&v)[3], T scale) {
+    T d[4], r[4];
+    so3_exp(v, scale, d);
+    quat_mul(q, d, r);
+    q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = r[3];
+}
+
+// log(other^* * q)
+template <class T> UKFB_DEV void so3_boxminus(const T (&q)[4], const T (&other)[4], T (&r)[3]) {
+    const T oc[4] = {-other[QX], -other[QY], -other[QZ], other[QW]};
+    T d[4];
+    quat_mul(oc, q, d);
+    so3_log(d, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-filter inputs of the process models (wave-resident scalars)
+// ---------------------------------------------------------------------------------------------
+template <class T> struct ProcIn {
+    T dt;
+    T a[3];       // Pose: acc.mu ; Orient: acceleration.mu
+    T w[3];       // Orient: rotation_rate.mu
+    bool use_acc; // Pose: acc.mu.allFinite()   (PoseUKF.cpp:188)
+    T ninv_tau_g, ninv_tau_a;  // Orient: -1/tau
+    T earth[3];
+};
+
+// ---------------------------------------------------------------------------------------------
+// PoseWithVelocity (PoseWithVelocity.hpp:18-23): p[0..2] q[3..6] v[7..9] w[10..12]
+// ---------------------------------------------------------------------------------------------
+template <class T> struct PoseM {
+    static constexpr int S = 13, D = 12, MODEL = 0;
+    enum { P = 0, Q = 3, V = 7, W = 10 };
+
+    static UKFB_DEV void boxplus(T (&x)[13], const T (&d)[12]) {
+        x[0] += d[0]; x[1] += d[1]; x[2] += d[2];
+        T q[4] = {x[3], x[4], x[5], x[6]};
+        const T dv[3] = {d[3], d[4], d[5]};
+        so3_boxplus(q, dv, T(1));
+        x[3] = q[0]; x[4] = q[1]; x[5] = q[2]; x[6] = q[3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[7 + k] += d[6 + k];
+    }
+    static UKFB_DEV void boxminus(const T (&x)[13], const T (&y)[13], T (&d)[12]) {
+        d[0] = x[0] - y[0]; d[1] = x[1] - y[1]; d[2] = x[2] - y[2];
+        const T qx[4] = {x[3], x[4], x[5], x[6]}, qy[4] = {y[3], y[4], y[5], y[6]};
+        T r[3];
+        so3_boxminus(qx, qy, r);
+        d[3] = r[0]; d[4] = r[1]; d[5] = r[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[6 + k] = x[7 + k] - y[7 + k];
+    }
+    // processModel / processModelWithAcceleration (PoseUKF.cpp:75-97)
+    static UKFB_DEV void process(T (&x)[13], const ProcIn<T>& in) {
+        if (in.use_acc) {
+            x[7] += in.dt * in.a[0]; x[8] += in.dt * in.a[1]; x[9] += in.dt * in.a[2];
+        }
+        T q[4] = {x[3], x[4], x[5], x[6]};
+        const T v[3] = {x[7], x[8], x[9]}, w[3] = {x[10], x[11], x[12]};
+        T rv[3], rw[3];
+        quat_rotate(q, v, rv);
+        x[0] += in.dt * rv[0]; x[1] += in.dt * rv[1]; x[2] += in.dt * rv[2];
+        quat_rotate(q, w, rw);
+        so3_boxplus(q, rw, in.dt);
+        x[3] = q[0]; x[4] = q[1]; x[5] = q[2]; x[6] = q[3];
+    }
+    static UKFB_DEV void orientation(const T (&x)[13], T (&q)[4]) {
+        q[0] = x[3]; q[1] = x[4]; q[2] = x[5]; q[3] = x[6];
+    }
+    // measurement models (PoseUKF.cpp:7-69).  z[0..2] vector part (unused entries 0), for
+    // MEAS_ORIENT_SO3 z[0..3] = orientation quaternion.  Returns nothing; `mid` in 0..8.
+    static UKFB_DEV void measure(const T (&x)[13], int mid, T (&z)[4]) {
+        // candidates: p(0..2) v(3..5) w(6..8)
+        const T cand[9] = {x[0], x[1], x[2], x[7], x[8], x[9], x[10], x[11], x[12]};
+        // selection table: first index and second/third per model
+        //   POS3 0,1,2 | POS_XY 0,1 | POS_Z 2 | VEL3 3,4,5 | VEL_XY 3,4 | VEL_Z 5 | XVEL_YAWVEL 3,8 | ANGVEL3 6,7,8
+        int i0 = -1, i1 = -1, i2 = -1;
+        if (mid == 0) { i0 = 0; i1 = 1; i2 = 2; }
+        else if (mid == 1) { i0 = 0; i1 = 1; }
+        else if (mid == 2) { i0 = 2; }
+        else if (mid == 4) { i0 = 3; i1 = 4; i2 = 5; }
+        else if (mid == 5) { i0 = 3; i1 = 4; }
+        else if (mid == 6) { i0 = 5; }
+        else if (mid == 7) { i0 = 3; i1 = 8; }
+        else if (mid == 8) { i0 = 6; i1 = 7; i2 = 8; }
+        T z0 = T(0), z1 = T(0), z2 = T(0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            z0 = (i0 == s) ? cand[s] : z0;
+            z1 = (i1 == s) ? cand[s] : z1;
+            z2 = (i2 == s) ? cand[s] : z2;
+        }
+        const bool so3 = (mid == 3);
+        z[0] = so3 ? x[3] : z0;
+        z[1] = so3 ? x[4] : z1;
+        z[2] = so3 ? x[5] : z2;
+        z[3] = so3 ? x[6] : T(0);
+    }
+    static UKFB_DEV int meas_dim(int mid) {
+        return (mid == 2 || mid == 6) ? 1 : ((mid == 1 || mid == 5 || mid == 7) ? 2 : 3);
+    }
+    static UKFB_DEV bool meas_valid(int mid) { return mid >= 0 && mid <= 8; }
+    static UKFB_DEV bool meas_is_so3(int mid) { return mid == 3; }
+    static constexpr bool CHECK_MEAS_FINITE = false;  // PoseUKF never calls checkMeasurment
+};
+
+// ---------------------------------------------------------------------------------------------
+// OrientationState (OrientationState.hpp:20-26): q[0..3] v[4..6] bg[7..9] ba[10..12] g[13]
+// ---------------------------------------------------------------------------------------------
+template <class T> struct OrientM {
+    static constexpr int S = 14, D = 13, MODEL = 1;
+
+    static UKFB_DEV void boxplus(T (&x)[14], const T (&d)[13]) {
+        T q[4] = {x[0], x[1], x[2], x[3]};
+        const T dv[3] = {d[0], d[1], d[2]};
+        so3_boxplus(q, dv, T(1));
+        x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) x[4 + k] += d[3 + k];
+    }
+    static UKFB_DEV void boxminus(const T (&x)[14], const T (&y)[14], T (&d)[13]) {
+        const T qx[4] = {x[0], x[1], x[2], x[3]}, qy[4] = {y[0], y[1], y[2], y[3]};
+        T r[3];
+        so3_boxminus(qx, qy, r);
+        d[0] = r[0]; d[1] = r[1]; d[2] = r[2];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d[3 + k] = x[4 + k] - y[4 + k];
+    }
+    // processModel (OrientationUKF.cpp:12-32)
+    static UKFB_DEV void process(T (&x)[14], const ProcIn<T>& in) {
+        T q[4] = {x[0], x[1], x[2], x[3]};
+        const T t[3] = {in.w[0] - x[7], in.w[1] - x[8], in.w[2] - x[9]};
+        T av[3];
+        quat_rotate(q, t, av);
+        av[0] -= in.earth[0]; av[1] -= in.earth[1]; av[2] -= in.earth[2];
+        so3_boxplus(q, av, in.dt);
+        x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+        const T u[3] = {in.a[0] - x[10], in.a[1] - x[11], in.a[2] - x[12]};
+        T acc[3];
+        quat_rotate(q, u, acc);  // already updated orientation (:22)
+        acc[2] -= x[13];
+        x[4] += in.dt * acc[0]; x[5] += in.dt * acc[1]; x[6] += in.dt * acc[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            x[7 + k] += in.dt * (in.ninv_tau_g * x[7 + k]);
+            x[10 + k] += in.dt * (in.ninv_tau_a * x[10 + k]);
+        }
+    }
+    static UKFB_DEV void orientation(const T (&x)[14], T (&q)[4]) {
+        q[0] = x[0]; q[1] = x[1]; q[2] = x[2]; q[3] = x[3];
+    }
+    // velocityMeasurementModel (OrientationUKF.cpp:34-39): q.inverse() * v
+    static UKFB_DEV void measure(const T (&x)[14], int, T (&z)[4]) {
+        const T n2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+        const T qi[4] = {-x[0] / n2, -x[1] / n2, -x[2] / n2, x[3] / n2};
+        const T v[3] = {x[4], x[5], x[6]};
+        T r[3];
+        quat_rotate(qi, v, r);
+        z[0] = r[0]; z[1] = r[1]; z[2] = r[2]; z[3] = T(0);
+    }
+    static UKFB_DEV int meas_dim(int) { return 3; }
+    static UKFB_DEV bool meas_valid(int mid) { return mid == 9; }
+    static UKFB_DEV bool meas_is_so3(int) { return false; }
+    static constexpr bool CHECK_MEAS_FINITE = true;  // OrientationUKF.cpp:67 checkMeasurment
+};
+
+}  // namespace ukfb

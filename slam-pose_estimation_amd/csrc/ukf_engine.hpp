@@ -1,0 +1,80 @@
+// ukf_engine.hpp -- host-side state of one batched UKF engine and the launch request that the
+// C-ABI (ukf_batch.hip) hands to the per-(precision, model) translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ukf_batch.h"
+
+struct ukfb_engine {
+    int model = 0, prec = 0, device = 0;
+    int64_t cap = 0;
+    int S = 0, D = 0, PK = 0;
+    size_t tsize = 8;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ukfb_config cfg{};
+
+    // per-filter device state
+    void* mu = nullptr;          // [cap][S]   engine precision
+    void* cov = nullptr;         // [cap][PK]  packed lower triangle
+    uint32_t* status = nullptr;  // [cap]
+    uint8_t* init = nullptr;     // [cap]
+    int64_t* last_ts = nullptr;  // [cap]
+
+    // process noise: batch-uniform D*D, or per filter after ukfb_set_process_noise_per_filter
+    void* Rn = nullptr;
+    bool Rn_per_filter = false;
+    std::vector<double> Rn_host;  // uniform copy
+
+    // latched inputs
+    void* in_a = nullptr;  // Pose acc.mu / Orient acceleration.mu   [cap][3]
+    void* in_b = nullptr;  // Orient rotation_rate.mu                [cap][3]
+    const void* in_a_bound = nullptr;
+    const void* in_b_bound = nullptr;
+    double acc_cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // Measurement.hpp:12 (Identity)
+    double tau_g = 1.0, tau_a = 1.0, earth[3] = {0, 0, 0};
+
+    // staging for host-pointer entry points
+    void* z_stage = nullptr;        // [cap][3]
+    void* Q_stage = nullptr;        // [cap][9]
+    int32_t* meas_stage = nullptr;  // [cap]
+    uint8_t* active_stage = nullptr;
+    double* dt_stage = nullptr;
+    int64_t* ts_stage = nullptr;
+    uint32_t* reduce_word = nullptr;  // status OR-reduction target
+
+    // last launch (for bench.py / profiles)
+    std::string last_kernel;
+    int last_lds = 0, last_fpw = 0;
+    int64_t last_grid = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace ukfb {
+
+// Untyped launch request; the typed KArgs<T> is built inside the (T, M) translation unit.
+struct LaunchReq {
+    bool do_predict = false, do_update = false;
+    double dt_uniform = 0.0;
+    const double* dt_dev = nullptr;
+    const int64_t* ts_dev = nullptr;
+    int meas_uniform = -1;
+    const int32_t* meas_dev = nullptr;
+    const void* z_dev = nullptr;
+    const void* Q_dev = nullptr;
+    const uint8_t* active_dev = nullptr;
+};
+
+int launch_pose_f64(ukfb_engine* e, const LaunchReq& r);
+int launch_pose_f32(ukfb_engine* e, const LaunchReq& r);
+int launch_orient_f64(ukfb_engine* e, const LaunchReq& r);
+int launch_orient_f32(ukfb_engine* e, const LaunchReq& r);
+
+void set_error(const char* what, hipError_t err);
+
+}  // namespace ukfb

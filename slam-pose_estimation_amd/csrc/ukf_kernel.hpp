@@ -1,0 +1,721 @@
+// ukf_kernel.hpp -- the fused UKF predict / update / cycle kernel for gfx950 (MI355X).
+//
+// Work decomposition (MI355X-first):
+//   * one workgroup = ONE wavefront of 64 lanes; no cross-wave communication, so the only
+//     synchronisation is wave-local LDS ordering.
+//   * the wavefront is split into 64/G groups of G lanes (G = 16, 32 or 64); each group owns one
+//     filter for the whole launch.  G = 16 is one DPP row per filter and packs 4 filters per
+//     wavefront; G = 64 is the literal "one wavefront per filter" layout.
+//   * a filter's mean, covariance rows, sigma points and measurement sigma points live in VGPRs;
+//     the Cholesky factor (column-major), the per-sigma-point tangent deltas and small
+//     matrices live in that group's LDS slice.  HBM is touched once on entry (mean + packed lower
+//     triangle + per-call inputs) and once on exit.
+//   * phases, per group:  row-per-lane Cholesky -> lane-per-sigma-point spread (boxplus) ->
+//     process / measurement model -> iterated manifold mean (boxminus + lane-column sums) ->
+//     lane-per-entry covariance recombination -> gain / downdate -> apply_delta resampling.
+//
+// The arithmetic replaces ukfom::ukf<WState>::predict / update as reached from the reference at
+// PoseUKF.cpp:114-172,192,195 and OrientationUKF.cpp:69,88 (algorithm: SURVEY.md Appendix A).
+#pragma once
+
+#include "ukf_device.hpp"
+
+namespace ukfb {
+
+enum : uint32_t {
+    ST_OK = 0u,
+    ST_SKIPPED_FIRST_TS = 1u << 0,
+    ST_SKIPPED_SMALL_DT = 1u << 1,
+    ST_ERR_NEG_DT = 1u << 2,
+    ST_ERR_DT_TOO_LARGE = 1u << 3,
+    ST_ERR_NONFINITE_MEAS = 1u << 4,
+    ST_ERR_CHOLESKY = 1u << 5,
+    ST_WARN_MEAN_NOCONV = 1u << 6,
+    ST_UNINITIALISED = 1u << 7,
+    ST_INACTIVE = 1u << 8,
+    ST_REJECTED_GATE = 1u << 9,
+};
+
+template <class T> struct KArgs {
+    int64_t n;
+    T* mu;                       // [n][S]
+    T* cov;                      // [n][PK] packed lower triangle, row-major
+    uint32_t* status;            // [n]
+    const uint8_t* initialised;  // [n]
+    // ---- predict
+    const T* Rn;                 // process_noise_cov, D*D row-major; per filter if Rn_stride != 0
+    int64_t Rn_stride;
+    const T* in_a;               // Pose: acc.mu [n][3] (may be null) ; Orient: acceleration.mu [n][3]
+    const T* in_b;               // Orient: rotation_rate.mu [n][3]
+    T acc_cov[9];                // Pose: acceleration.cov (batch-uniform)
+    T ninv_tau_g, ninv_tau_a;    // Orient: -1/tau
+    T earth[3];                  // Orient: earth rotation
+    double dt_uniform;
+    const double* dt;            // per filter, may be null
+    const int64_t* ts;           // per filter timestamps (us), may be null
+    int64_t* last_ts;            // [n]
+    double min_dt, max_dt;
+    // ---- update
+    int meas_uniform;
+    const int32_t* meas;         // per filter, may be null
+    const T* z;                  // [n][3]
+    const T* Q;                  // [n][9]
+    const uint8_t* active;       // [n], may be null
+    // ---- ukfom constants
+    T mean_tol;
+    int mean_max_it;
+    T gate_chi2;                 // < 0: accept any
+};
+
+// LDS slice of one filter, in scalars of T.
+template <class T, class M> struct Layout {
+    static constexpr int VEC = 16 / int(sizeof(T));
+    static constexpr int D = M::D, S = M::S, N = 2 * D + 1;
+    static constexpr int LS = (D + VEC - 1) / VEC * VEC;  // column stride of the Cholesky factor
+    static constexpr int DS = 16;                         // row stride of the delta table
+    static constexpr int ZOFF = D;                        // measurement deltas behind the state deltas
+    static constexpr int LC_OFF = 0;                      // D*LS : packed Sigma staging / L columns / small matrices
+    static constexpr int DX_OFF = D * LS;                 // N*DS : [dx(0..D-1) | dz(0..2)] per sigma point
+    static constexpr int MISC_OFF = DX_OFF + N * DS;      // 72   : MU MD ROT ZQ DEL
+    static constexpr int PF = MISC_OFF + 72;
+    // small matrices that reuse the (dead) factor region between two Choleskys
+    static constexpr int SMAT = 0, CXZ = 12, KMAT = 52, KEND = 92;
+    static_assert(D + 3 <= DS, "delta row too small");
+    static_assert(KEND <= D * LS, "small-matrix scratch exceeds the factor region");
+    static_assert(PF % VEC == 0, "slice must keep 16-byte alignment");
+};
+
+template <class T, class M> constexpr int lds_bytes_per_filter() { return Layout<T, M>::PF * int(sizeof(T)); }
+
+UKFB_DEV void wsync() { __syncthreads(); }  // one wavefront per workgroup: no s_barrier wait across waves
+
+template <int G> UKFB_DEV double gshfl(double v, int src) { return __shfl(v, src, G); }
+template <int G> UKFB_DEV float gshfl(float v, int src) { return __shfl(v, src, G); }
+
+// Row-per-lane right-looking Cholesky.  Lane l < D holds row l (entries 0..l) in a[]; column k of
+// the factor is published to Lc (column-major, stride LS, zeros above the diagonal) as soon as it
+// is final and read back (LDS broadcast) for the trailing update.  false: a pivot was <= 0
+// (Eigen LLT: NumericalIssue).
+template <class T, int D, int LS, int G> UKFB_DEV bool chol_rows_to_lds(T (&a)[D], T* Lc, int l) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const T akk = gshfl<G>(a[k], k);
+        ok = ok && (akk > T(0));
+        const T d = m_sqrt(akk);
+        const T inv = T(1) / d;
+        const T lk = (l > k) ? a[k] * inv : ((l == k) ? d : T(0));
+        if (l < D) Lc[k * LS + l] = lk;
+        wsync();
+#pragma unroll
+        for (int c = k + 1; c < D; ++c) a[c] -= lk * Lc[k * LS + c];
+    }
+    return ok;
+}
+
+// Sigma point i of the set {mu+d0, mu+(d0+L col j), mu+(d0-L col j)} (ukfom generate_sigma_points).
+template <class T, class M, int LS, bool HAS_D0>
+UKFB_DEV void sigma_point(const T (&mu)[M::S], const T* Lc, const T (&d0)[M::D], int i, T (&x)[M::S]) {
+    constexpr int D = M::D, S = M::S;
+    const int j = (i > 0) ? ((i - 1) >> 1) : 0;
+    const T sgn = (i == 0) ? T(0) : ((i & 1) ? T(1) : T(-1));
+    T d[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const T lc = sgn * Lc[j * LS + c];
+        d[c] = HAS_D0 ? (d0[c] + lc) : lc;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] = mu[s];
+    M::boxplus(x, d);
+}
+
+// ukfom meanSigmaPoints on the state manifold: lanes hold the sigma points, deltas go through the
+// group's LDS table, lanes 0..D-1 each sum one tangent component in sigma-point order.
+template <class T, class M, int G, int RND, int DS>
+UKFB_DEV bool mean_loop_state(const T (&X)[RND][M::S], T (&ref)[M::S], T* DX, T* MD, int l, T tol, int max_it) {
+    constexpr int D = M::D, S = M::S, N = 2 * D + 1;
+    bool active = true, conv = true;
+    int it = 0;
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < RND; ++r) {
+            const int i = l + G * r;
+            if (i < N) {
+                T d[D];
+                M::boxminus(X[r], ref, d);
+#pragma unroll
+                for (int c = 0; c < D; ++c) DX[i * DS + c] = d[c];
+            }
+        }
+        wsync();
+        if (l < D) {
+            T md = T(0);
+#pragma unroll 5
+            for (int i = 0; i < N; ++i) md += DX[i * DS + l];
+            MD[l] = md / T(N);
+        }
+        wsync();
+        T mdv[D];
+        T n2 = T(0);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            mdv[c] = MD[c];
+            n2 += mdv[c] * mdv[c];
+        }
+        T nref[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) nref[s] = ref[s];
+        M::boxplus(nref, mdv);
+#pragma unroll
+        for (int s = 0; s < S; ++s) ref[s] = active ? nref[s] : ref[s];
+        const T norm = m_sqrt(n2);
+        if (active) {
+            if (norm > tol) {
+                if (++it >= max_it) {
+                    active = false;
+                    conv = false;
+                }
+            } else {
+                active = false;
+            }
+        }
+        if (!__any(active)) break;
+    }
+    return conv;
+}
+
+// lower-triangle entry index -> (row, col)
+UKFB_DEV void tri_decode(int e, int& r, int& c) {
+    int rr = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
+    if (rr * (rr + 1) / 2 > e) --rr;
+    if ((rr + 1) * (rr + 2) / 2 <= e) ++rr;
+    r = rr;
+    c = e - rr * (rr + 1) / 2;
+}
+
+// 0.5 * sum_i DX[i][r] DX[i][c] for this lane's packed entries (ukfom covSigmaPoints).
+template <class T, int N, int DS, int EPL>
+UKFB_DEV void cov_entries(const T* DX, const int (&er)[EPL], const int (&ec)[EPL], T (&P)[EPL]) {
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) P[t] = T(0);
+#pragma unroll 2
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) P[t] += DX[i * DS + er[t]] * DX[i * DS + ec[t]];
+    }
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) P[t] *= T(0.5);
+}
+
+// Eigen fixed-size 3x3 inverse (cofactors / determinant)
+template <class T> UKFB_DEV void inverse3(const T (&m)[9], T (&r)[9]) {
+    const T c00 = m[4] * m[8] - m[5] * m[7];
+    const T c10 = m[7] * m[2] - m[8] * m[1];
+    const T c20 = m[1] * m[5] - m[2] * m[4];
+    const T det = c00 * m[0] + c10 * m[3] + c20 * m[6];
+    const T invdet = T(1) / det;
+    r[0] = c00 * invdet;
+    r[1] = c10 * invdet;
+    r[2] = c20 * invdet;
+    r[3] = (m[5] * m[6] - m[3] * m[8]) * invdet;
+    r[4] = (m[0] * m[8] - m[2] * m[6]) * invdet;
+    r[5] = (m[2] * m[3] - m[0] * m[5]) * invdet;
+    r[6] = (m[3] * m[7] - m[4] * m[6]) * invdet;
+    r[7] = (m[1] * m[6] - m[0] * m[7]) * invdet;
+    r[8] = (m[0] * m[4] - m[1] * m[3]) * invdet;
+}
+
+// One entry of the shaped process noise R (PoseUKF.cpp:183-191, OrientationUKF.cpp:82-86).
+template <class T, class M>
+UKFB_DEV T process_noise_entry(const T* Rn, const T* ROT, const KArgs<T>& a, const ProcIn<T>& pin, int r, int c) {
+    constexpr int D = M::D;
+    const T rn = Rn[r * D + c];
+    if (M::MODEL == 0 && pin.use_acc) {
+        // acceleration branch: raw process_noise_cov, block(6,6,3,3) = 2 acc.cov, no rotation, no dt
+        const bool vel = (r >= 6 && r < 9 && c >= 6 && c < 9);
+        const int k = vel ? ((r - 6) * 3 + (c - 6)) : 0;
+        T ac = T(0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) ac = (k == s) ? a.acc_cov[s] : ac;
+        return vel ? T(2) * ac : rn;
+    }
+    const int o = (r < 3 && c < 3) ? 0 : ((r >= 3 && r < 6 && c >= 3 && c < 6) ? 3 : -1);
+    T val = rn;
+    if (o >= 0) {
+        // (rot * B) * rot^T, entry (r-o, c-o)
+        const int rr = r - o, cc = c - o;
+        T acc = T(0);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            T tmp = T(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tmp += ROT[rr * 3 + k] * Rn[(o + k) * D + (o + m)];
+            acc += tmp * ROT[cc * 3 + m];
+        }
+        val = acc;
+    }
+    const T scale = (M::MODEL == 0) ? pin.dt : pin.dt * pin.dt;
+    return scale * val;
+}
+
+// minimum waves per SIMD the register allocator must leave room for (LDS admits about this many)
+template <class T> constexpr int min_waves_per_simd() { return sizeof(T) == 8 ? 2 : 4; }
+
+template <class T, class M, int G, bool DO_PREDICT, bool DO_UPDATE>
+__global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const KArgs<T> a) {
+    constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
+    using LY = Layout<T, M>;
+    constexpr int LS = LY::LS, DS = LY::DS, ZO = LY::ZOFF;
+    constexpr int FPW = 64 / G, RND = (N + G - 1) / G, EPL = (PK + G - 1) / G;
+    static_assert(G >= 16 && S <= G, "group too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int g = lane / G, l = lane % G;
+    const int64_t f = int64_t(blockIdx.x) * FPW + g;
+    const bool fvalid = f < a.n;
+    const int64_t fc = fvalid ? f : (a.n - 1);
+    T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
+    T* Lc = base + LY::LC_OFF;
+    T* DX = base + LY::DX_OFF;
+    T* MS = base + LY::MISC_OFF;
+    T* MU = MS; T* MD = MS + 16; T* ROT = MS + 32; T* ZQ = MS + 44; T* DEL = MS + 56;
+
+    // this lane's packed covariance entries
+    int er[EPL], ec[EPL];
+    bool ev[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int e = l + G * t;
+        ev[t] = e < PK;
+        tri_decode(ev[t] ? e : (PK - 1), er[t], ec[t]);
+    }
+
+    uint32_t st = ST_OK;
+    const bool live = fvalid && (a.initialised[fc] != 0);
+    if (fvalid && !live) st |= ST_UNINITIALISED;
+
+    // ---- time gate (UnscentedKalmanFilter.hpp:83-125)
+    bool do_p = false, p_error = false;
+    T dtT = T(0);
+    if constexpr (DO_PREDICT) {
+        double dt;
+        bool first = false;
+        if (a.ts) {
+            const int64_t last = a.last_ts[fc], ts = a.ts[fc];
+            first = (last == 0);
+            dt = first ? 0.0 : double(ts - last) / 1000000.0;
+            if (live && l == 0 && (first || dt > a.min_dt)) a.last_ts[fc] = ts;
+        } else {
+            dt = a.dt ? a.dt[fc] : a.dt_uniform;
+        }
+        if (live) {
+            if (first) st |= ST_SKIPPED_FIRST_TS;
+            else if (dt < 0.0) { st |= ST_ERR_NEG_DT; p_error = true; }
+            else if (dt <= a.min_dt) st |= ST_SKIPPED_SMALL_DT;
+            else if (dt > a.max_dt) { st |= ST_ERR_DT_TOO_LARGE; p_error = true; }
+            else do_p = true;
+        }
+        dtT = T(dt);
+    }
+
+    // ---- measurement selection
+    bool do_u = false;
+    int mid = -1;
+    if constexpr (DO_UPDATE) {
+        mid = a.meas ? a.meas[fc] : a.meas_uniform;
+        const bool act = M::meas_valid(mid) && (a.active ? a.active[fc] != 0 : true);
+        do_u = live && act && !p_error;
+        if (live && !do_u) st |= ST_INACTIVE;
+    }
+
+    // ---- load: packed covariance + mean -> LDS -> registers (mean replicated, row l on lane l)
+#pragma unroll
+    for (int t = 0; t < EPL; ++t)
+        if (ev[t]) Lc[l + G * t] = a.cov[fc * PK + l + G * t];
+    if (l < S) MU[l] = a.mu[fc * S + l];
+    wsync();
+    T mu_r[S], rowv[D];
+#pragma unroll
+    for (int s = 0; s < S; ++s) mu_r[s] = MU[s];
+#pragma unroll
+    for (int j = 0; j < D; ++j) rowv[j] = (l < D && j <= l) ? Lc[l * (l + 1) / 2 + j] : T(0);
+    wsync();
+
+    T zero_d[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) zero_d[c] = T(0);
+
+    bool p_commit = false, u_commit = false;
+    T Pn[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) Pn[t] = T(0);
+
+    // =========================================================================== predict
+    if constexpr (DO_PREDICT) {
+        if (__any(do_p)) {
+            ProcIn<T> pin;
+            pin.dt = dtT;
+            pin.ninv_tau_g = a.ninv_tau_g;
+            pin.ninv_tau_a = a.ninv_tau_a;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pin.earth[k] = a.earth[k];
+                pin.a[k] = a.in_a ? a.in_a[fc * 3 + k] : T(NAN);
+                pin.w[k] = a.in_b ? a.in_b[fc * 3 + k] : T(0);
+            }
+            pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
+
+            {   // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81)
+                T q[4], rot[9];
+                M::orientation(mu_r, q);
+                quat_to_matrix(q, rot);
+                if (l == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) ROT[k] = rot[k];
+                }
+            }
+
+            T arow[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) arow[j] = rowv[j];
+            const bool ok = chol_rows_to_lds<T, D, LS, G>(arow, Lc, l);
+
+            T X[RND][S];
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const int i = min(l + G * r, N - 1);
+                sigma_point<T, M, LS, false>(mu_r, Lc, zero_d, i, X[r]);
+                M::process(X[r], pin);
+            }
+            T ref[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) ref[s] = gshfl<G>(X[0][s], 0);
+
+            const bool conv = mean_loop_state<T, M, G, RND, DS>(X, ref, DX, MD, l, a.mean_tol, a.mean_max_it);
+
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const int i = l + G * r;
+                if (i < N) {
+                    T d[D];
+                    M::boxminus(X[r], ref, d);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) DX[i * DS + c] = d[c];
+                }
+            }
+            wsync();
+            cov_entries<T, N, DS, EPL>(DX, er, ec, Pn);
+            const T* Rn = a.Rn + fc * a.Rn_stride;
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) Pn[t] += process_noise_entry<T, M>(Rn, ROT, a, pin, er[t], ec[t]);
+            wsync();
+
+            p_commit = do_p && ok;
+            if (do_p && !ok) st |= ST_ERR_CHOLESKY;
+            if (p_commit && !conv) st |= ST_WARN_MEAN_NOCONV;
+#pragma unroll
+            for (int t = 0; t < EPL; ++t)
+                if (ev[t]) Lc[l + G * t] = Pn[t];
+#pragma unroll
+            for (int s = 0; s < S; ++s) mu_r[s] = p_commit ? ref[s] : mu_r[s];
+            wsync();
+            if constexpr (DO_UPDATE) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const T v = (l < D && j <= l) ? Lc[l * (l + 1) / 2 + j] : T(0);
+                    rowv[j] = p_commit ? v : rowv[j];
+                }
+                wsync();
+            }
+        }
+    }
+
+    // =========================================================================== update
+    T mu2[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) mu2[s] = mu_r[s];
+    T Pu[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) Pu[t] = T(0);
+
+    if constexpr (DO_UPDATE) {
+        if (__any(do_u)) {
+            if (l < 12) ZQ[l] = (l < 3) ? a.z[fc * 3 + l] : a.Q[fc * 9 + (l - 3)];
+            wsync();
+            T zin[3], Qm[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) zin[k] = ZQ[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Qm[k] = ZQ[3 + k];
+            if (M::CHECK_MEAS_FINITE) {
+                bool fin = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fin = fin && m_finite(zin[k]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) fin = fin && m_finite(Qm[k]);
+                if (do_u && !fin) {
+                    st |= ST_ERR_NONFINITE_MEAS;
+                    do_u = false;
+                }
+            }
+            const int midc = M::meas_valid(mid) ? mid : (M::MODEL == 0 ? 0 : 9);
+            const int m = M::meas_dim(midc);
+            const bool so3 = M::meas_is_so3(midc);
+            // unused trailing dimensions are decoupled: Q = I there, z = h = 0
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (r >= m || c >= m) Qm[r * 3 + c] = (r == c) ? T(1) : T(0);
+            T zval[4];
+            {
+                T qe[4];
+                so3_exp(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
+#pragma unroll
+                for (int k = 0; k < 3; ++k) zval[k] = so3 ? qe[k] : ((k < m) ? zin[k] : T(0));
+                zval[3] = so3 ? qe[3] : T(0);
+            }
+
+            T arow[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) arow[j] = rowv[j];
+            const bool ok1 = chol_rows_to_lds<T, D, LS, G>(arow, Lc, l);
+
+            T X[RND][S], Z[RND][4];
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const int i = min(l + G * r, N - 1);
+                sigma_point<T, M, LS, false>(mu_r, Lc, zero_d, i, X[r]);
+                M::measure(X[r], midc, Z[r]);
+            }
+            // ---- mean of Z (ukfom meanSigmaPoints on the measurement space)
+            T zref[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zref[k] = gshfl<G>(Z[0][k], 0);
+            bool zconv = true;
+            {
+                bool active = true;
+                int it = 0;
+                for (;;) {
+#pragma unroll
+                    for (int r = 0; r < RND; ++r) {
+                        const int i = l + G * r;
+                        if (i < N) {
+                            T dz[3];
+                            if (so3) so3_boxminus(Z[r], zref, dz);
+                            else {
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) dz[k] = Z[r][k] - zref[k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) DX[i * DS + ZO + k] = dz[k];
+                        }
+                    }
+                    wsync();
+                    if (l < 3) {
+                        T md = T(0);
+#pragma unroll 5
+                        for (int i = 0; i < N; ++i) md += DX[i * DS + ZO + l];
+                        MD[l] = md / T(N);
+                    }
+                    wsync();
+                    T mdv[3];
+                    T n2 = T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        mdv[k] = MD[k];
+                        n2 += mdv[k] * mdv[k];
+                    }
+                    T nz[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nz[k] = zref[k];
+                    if (so3) so3_boxplus(nz, mdv, T(1));
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) nz[k] += mdv[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) zref[k] = active ? nz[k] : zref[k];
+                    const T norm = m_sqrt(n2);
+                    if (active) {
+                        if (norm > a.mean_tol) {
+                            if (++it >= a.mean_max_it) {
+                                active = false;
+                                zconv = false;
+                            }
+                        } else {
+                            active = false;
+                        }
+                    }
+                    if (!__any(active)) break;
+                }
+            }
+            // ---- final deltas: dz_i = Z_i - zbar, dx_i = X_i - mu
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const int i = l + G * r;
+                if (i < N) {
+                    T dz[3];
+                    if (so3) so3_boxminus(Z[r], zref, dz);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) dz[k] = Z[r][k] - zref[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) DX[i * DS + ZO + k] = dz[k];
+                    T dx[D];
+                    M::boxminus(X[r], mu_r, dx);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) DX[i * DS + c] = dx[c];
+                }
+            }
+            wsync();
+            // ---- S = 0.5 sum dz dz^T + Q (9 entries), Cxz = 0.5 sum dx dz^T (3D entries)
+            {
+                constexpr int NE = 9 + 3 * D, TPL = (NE + G - 1) / G;
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) {
+                    const int qi = l + G * t;
+                    if (qi < NE) {
+                        const bool isS = qi < 9;
+                        const int ra = isS ? (ZO + qi / 3) : ((qi - 9) / 3);
+                        const int cb = ZO + (isS ? (qi % 3) : ((qi - 9) % 3));
+                        T acc = T(0);
+#pragma unroll 5
+                        for (int i = 0; i < N; ++i) acc += DX[i * DS + ra] * DX[i * DS + cb];
+                        acc *= T(0.5);
+                        if (isS) {
+                            T qv = T(0);
+#pragma unroll
+                            for (int s = 0; s < 9; ++s) qv = (qi == s) ? Qm[s] : qv;
+                            Lc[LY::SMAT + qi] = acc + qv;
+                        } else {
+                            Lc[LY::CXZ + (qi - 9)] = acc;
+                        }
+                    }
+                }
+            }
+            wsync();
+            // ---- gain, innovation, downdate (ukfom update)
+            T Sm[9], Si[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Sm[k] = Lc[LY::SMAT + k];
+            inverse3(Sm, Si);
+            T innov[3];
+            if (so3) so3_boxminus(zval, zref, innov);
+            else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) innov[k] = zval[k] - zref[k];
+            }
+            T maha = T(0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) maha += innov[r] * Si[r * 3 + c] * innov[c];
+            const bool accept = (a.gate_chi2 < T(0)) || (maha <= a.gate_chi2);
+
+            const int la = (l < D) ? l : (D - 1);
+            T Kr[3], KSr[3];
+            {
+                T cx[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cx[k] = Lc[LY::CXZ + la * 3 + k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    T s = T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s += cx[k] * Si[k * 3 + c];
+                    Kr[c] = s;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    T s = T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s += Kr[k] * Sm[k * 3 + c];
+                    KSr[c] = s;
+                }
+                T del = T(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) del += Kr[k] * innov[k];
+                if (l < D) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Lc[LY::KMAT + l * 3 + k] = Kr[k];
+                    DEL[l] = del;
+                }
+            }
+            wsync();
+            T arow2[D], dl[D];
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += KSr[k] * Lc[LY::KMAT + b * 3 + k];
+                arow2[b] = rowv[b] - s;
+                dl[b] = DEL[b];
+            }
+            wsync();
+            const bool ok2 = chol_rows_to_lds<T, D, LS, G>(arow2, Lc, l);
+
+            // ---- applyDelta: resample around mu + delta
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const int i = min(l + G * r, N - 1);
+                sigma_point<T, M, LS, true>(mu_r, Lc, dl, i, X[r]);
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) mu2[s] = gshfl<G>(X[0][s], 0);
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const int i = l + G * r;
+                if (i < N) {
+                    T d[D];
+                    M::boxminus(X[r], mu2, d);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) DX[i * DS + c] = d[c];
+                }
+            }
+            wsync();
+            cov_entries<T, N, DS, EPL>(DX, er, ec, Pu);
+            wsync();
+
+            if (do_u) {
+                if (!ok1 || (accept && !ok2)) st |= ST_ERR_CHOLESKY;
+                else if (!accept) st |= ST_REJECTED_GATE;
+                if (ok1 && !zconv) st |= ST_WARN_MEAN_NOCONV;
+            }
+            u_commit = do_u && ok1 && ok2 && accept;
+        }
+    }
+
+    // =========================================================================== commit
+    const bool changed = p_commit || u_commit;
+    if (__any(changed)) {
+        if (u_commit) {
+#pragma unroll
+            for (int t = 0; t < EPL; ++t)
+                if (ev[t]) Lc[l + G * t] = Pu[t];
+        } else if (DO_UPDATE && p_commit) {
+            if (l < D) {
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (j <= l) Lc[l * (l + 1) / 2 + j] = rowv[j];
+            }
+        }
+        if (l == 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) MU[s] = u_commit ? mu2[s] : mu_r[s];
+        }
+        wsync();
+        if (changed && fvalid) {
+#pragma unroll
+            for (int t = 0; t < EPL; ++t)
+                if (ev[t]) a.cov[f * PK + l + G * t] = Lc[l + G * t];
+            if (l < S) a.mu[f * S + l] = MU[l];
+        }
+    }
+    if (fvalid && l == 0) a.status[f] = st;
+}
+
+}  // namespace ukfb

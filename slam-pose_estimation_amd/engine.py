@@ -1,0 +1,327 @@
+"""ctypes binding of the C-ABI in include/ukf_batch.h (lib/libukf_batch.so).
+
+This is plumbing: every numeric operation happens in the HIP kernels behind the C-ABI.  There is no
+CPU fallback -- if the shared library or a HIP device is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libukf_batch.so")
+
+MODEL_POSE, MODEL_ORIENT = 0, 1
+F64, F32 = 0, 1
+
+MEAS_NONE = -1
+MEAS_POS3, MEAS_POS_XY, MEAS_POS_Z, MEAS_ORIENT_SO3, MEAS_VEL3 = 0, 1, 2, 3, 4
+MEAS_VEL_XY, MEAS_VEL_Z, MEAS_XVEL_YAWVEL, MEAS_ANGVEL3, MEAS_ORIENT_BODYVEL3 = 5, 6, 7, 8, 9
+
+ST_OK = 0
+ST_SKIPPED_FIRST_TS = 1 << 0
+ST_SKIPPED_SMALL_DT = 1 << 1
+ST_ERR_NEG_DT = 1 << 2
+ST_ERR_DT_TOO_LARGE = 1 << 3
+ST_ERR_NONFINITE_MEAS = 1 << 4
+ST_ERR_CHOLESKY = 1 << 5
+ST_WARN_MEAN_NOCONV = 1 << 6
+ST_UNINITIALISED = 1 << 7
+ST_INACTIVE = 1 << 8
+ST_REJECTED_GATE = 1 << 9
+
+# every symbol include/ukf_batch.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ukfb_default_config", "ukfb_create", "ukfb_destroy", "ukfb_last_error", "ukfb_set_config", "ukfb_get_config",
+    "ukfb_sync", "ukfb_describe", "ukfb_initialize", "ukfb_get_state", "ukfb_get_status", "ukfb_get_status_summary",
+    "ukfb_set_last_measurement_time", "ukfb_get_last_measurement_time", "ukfb_device_views",
+    "ukfb_set_process_noise", "ukfb_set_process_noise_per_filter", "ukfb_get_process_noise",
+    "ukfb_pose_set_acceleration", "ukfb_pose_bind_acceleration_dev", "ukfb_orient_set_params",
+    "ukfb_orient_set_inputs", "ukfb_orient_bind_inputs_dev", "ukfb_orient_get_rotation_rate", "ukfb_predict",
+    "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
+    "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_last_launch_info",
+    "ukfb_timer_begin", "ukfb_timer_end",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("mean_tol", C.c_double), ("mean_max_iter", C.c_int32), ("gate_chi2", C.c_double),
+                ("min_time_delta", C.c_double), ("max_time_delta", C.c_double), ("lanes_per_filter", C.c_int32)]
+
+
+class UkfbError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libukf_batch.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UkfbError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                            f"(make -C slam-pose_estimation_amd/csrc); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.ukfb_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().ukfb_last_error()
+        raise UkfbError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _devptr(x):
+    """Accept an int address, a torch tensor (data_ptr) or None."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class BatchUKF:
+    """A batch of independent UKFs resident on one MI355X (opaque ukfb_engine handle)."""
+
+    def __init__(self, model: int, precision: int, capacity: int, device: int = 0, stream=None,
+                 lanes_per_filter: int = 0, **cfg):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _chk(self._lib.ukfb_create(C.byref(self._h), C.c_int(model), C.c_int(precision), C.c_int64(capacity),
+                                   C.c_int(device), C.c_void_p(stream) if stream else None), "ukfb_create")
+        self.model, self.precision, self.capacity, self.device = model, precision, int(capacity), device
+        self.S = 13 if model == MODEL_POSE else 14
+        self.D = 12 if model == MODEL_POSE else 13
+        self.PK = self.D * (self.D + 1) // 2
+        self.dtype = np.float64 if precision == F64 else np.float32
+        if lanes_per_filter or cfg:
+            self.configure(lanes_per_filter=lanes_per_filter, **cfg)
+
+    # ---- lifetime / config
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ukfb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def config(self) -> Config:
+        c = Config()
+        _chk(self._lib.ukfb_get_config(self._h, C.byref(c)), "ukfb_get_config")
+        return c
+
+    def configure(self, **kw):
+        c = self.config()
+        for k, v in kw.items():
+            if k == "lanes_per_filter" and not v:
+                continue
+            setattr(c, k, v)
+        _chk(self._lib.ukfb_set_config(self._h, C.byref(c)), "ukfb_set_config")
+
+    def sync(self):
+        _chk(self._lib.ukfb_sync(self._h), "ukfb_sync")
+
+    # ---- state
+    def initialize(self, mu, cov, first: int = 0):
+        mu = _f64(mu, (-1, self.S)); cov = _f64(cov, (-1, self.D, self.D))
+        _chk(self._lib.ukfb_initialize(self._h, C.c_int64(first), C.c_int64(mu.shape[0]), _pd(mu), _pd(cov)),
+             "ukfb_initialize")
+
+    def state(self, first: int = 0, count: Optional[int] = None, with_cov: bool = True):
+        count = self.capacity - first if count is None else count
+        mu = np.empty((count, self.S))
+        cov = np.empty((count, self.D, self.D)) if with_cov else None
+        init = np.empty(count, dtype=np.uint8)
+        _chk(self._lib.ukfb_get_state(self._h, C.c_int64(first), C.c_int64(count), _pd(mu), _pd(cov),
+                                      init.ctypes.data_as(C.POINTER(C.c_uint8))), "ukfb_get_state")
+        return (mu, cov, init.astype(bool)) if with_cov else (mu, init.astype(bool))
+
+    def status(self, first: int = 0, count: Optional[int] = None):
+        count = self.capacity - first if count is None else count
+        st = np.empty(count, dtype=np.uint32)
+        _chk(self._lib.ukfb_get_status(self._h, C.c_int64(first), C.c_int64(count),
+                                       st.ctypes.data_as(C.POINTER(C.c_uint32))), "ukfb_get_status")
+        return st
+
+    def status_summary(self) -> int:
+        v = C.c_uint32(0)
+        _chk(self._lib.ukfb_get_status_summary(self._h, C.byref(v)), "ukfb_get_status_summary")
+        return int(v.value)
+
+    def set_last_measurement_time(self, t_us, first: int = 0):
+        t = np.ascontiguousarray(t_us, dtype=np.int64)
+        _chk(self._lib.ukfb_set_last_measurement_time(self._h, C.c_int64(first), C.c_int64(t.size),
+                                                      t.ctypes.data_as(C.POINTER(C.c_int64))), "set_last_time")
+
+    def last_measurement_time(self, first: int = 0, count: Optional[int] = None):
+        count = self.capacity - first if count is None else count
+        t = np.empty(count, dtype=np.int64)
+        _chk(self._lib.ukfb_get_last_measurement_time(self._h, C.c_int64(first), C.c_int64(count),
+                                                      t.ctypes.data_as(C.POINTER(C.c_int64))), "get_last_time")
+        return t
+
+    def device_views(self):
+        mu, cov, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _chk(self._lib.ukfb_device_views(self._h, C.byref(mu), C.byref(cov), C.byref(st)), "ukfb_device_views")
+        return mu.value, cov.value, st.value
+
+    # ---- noise / inputs
+    def set_process_noise(self, R, first: Optional[int] = None):
+        R = _f64(R)
+        if R.ndim == 2:
+            _chk(self._lib.ukfb_set_process_noise(self._h, _pd(R)), "ukfb_set_process_noise")
+        else:
+            _chk(self._lib.ukfb_set_process_noise_per_filter(self._h, C.c_int64(first or 0), C.c_int64(R.shape[0]),
+                                                             _pd(R)), "ukfb_set_process_noise_per_filter")
+
+    def process_noise(self, filter_index: int = 0):
+        R = np.empty((self.D, self.D))
+        _chk(self._lib.ukfb_get_process_noise(self._h, C.c_int64(filter_index), _pd(R)), "ukfb_get_process_noise")
+        return R
+
+    def set_acceleration(self, acc_mu=None, acc_cov=None, first: int = 0):
+        am = _f64(acc_mu, (-1, 3)) if acc_mu is not None else None
+        ac = _f64(acc_cov, (3, 3)) if acc_cov is not None else None
+        n = am.shape[0] if am is not None else 0
+        _chk(self._lib.ukfb_pose_set_acceleration(self._h, C.c_int64(first), C.c_int64(n), _pd(am), _pd(ac)),
+             "ukfb_pose_set_acceleration")
+
+    def bind_acceleration_dev(self, acc_dev):
+        _chk(self._lib.ukfb_pose_bind_acceleration_dev(self._h, _devptr(acc_dev)), "ukfb_pose_bind_acceleration_dev")
+
+    def set_orient_params(self, gyro_bias_tau: float, acc_bias_tau: float, earth_rotation):
+        er = _f64(earth_rotation, (3,))
+        _chk(self._lib.ukfb_orient_set_params(self._h, C.c_double(gyro_bias_tau), C.c_double(acc_bias_tau), _pd(er)),
+             "ukfb_orient_set_params")
+
+    def set_orient_inputs(self, gyro=None, acc=None, first: int = 0):
+        g = _f64(gyro, (-1, 3)) if gyro is not None else None
+        a = _f64(acc, (-1, 3)) if acc is not None else None
+        n = g.shape[0] if g is not None else (a.shape[0] if a is not None else 0)
+        _chk(self._lib.ukfb_orient_set_inputs(self._h, C.c_int64(first), C.c_int64(n), _pd(g), _pd(a)),
+             "ukfb_orient_set_inputs")
+
+    def bind_orient_inputs_dev(self, gyro_dev, acc_dev):
+        _chk(self._lib.ukfb_orient_bind_inputs_dev(self._h, _devptr(gyro_dev), _devptr(acc_dev)),
+             "ukfb_orient_bind_inputs_dev")
+
+    def rotation_rate(self, first: int = 0, count: Optional[int] = None):
+        count = self.capacity - first if count is None else count
+        out = np.empty((count, 3))
+        _chk(self._lib.ukfb_orient_get_rotation_rate(self._h, C.c_int64(first), C.c_int64(count), _pd(out)),
+             "ukfb_orient_get_rotation_rate")
+        return out
+
+    # ---- predict
+    def predict(self, dt):
+        if np.isscalar(dt):
+            _chk(self._lib.ukfb_predict(self._h, C.c_double(float(dt))), "ukfb_predict")
+        else:
+            d = _f64(dt, (self.capacity,))
+            _chk(self._lib.ukfb_predict_dt(self._h, _pd(d)), "ukfb_predict_dt")
+
+    def predict_timestamps(self, ts_us):
+        t = np.ascontiguousarray(ts_us, dtype=np.int64).reshape(self.capacity)
+        _chk(self._lib.ukfb_predict_timestamps(self._h, t.ctypes.data_as(C.POINTER(C.c_int64))),
+             "ukfb_predict_timestamps")
+
+    def predict_dt_dev(self, dt_dev):
+        _chk(self._lib.ukfb_predict_dt_dev(self._h, _devptr(dt_dev)), "ukfb_predict_dt_dev")
+
+    def predict_timestamps_dev(self, ts_dev):
+        _chk(self._lib.ukfb_predict_timestamps_dev(self._h, _devptr(ts_dev)), "ukfb_predict_timestamps_dev")
+
+    # ---- update
+    def update(self, meas_model, z, Q, active=None):
+        z = _f64(z, (self.capacity, 3)); Q = _f64(Q, (self.capacity, 3, 3))
+        if np.isscalar(meas_model):
+            act = np.ascontiguousarray(active, dtype=np.uint8) if active is not None else None
+            _chk(self._lib.ukfb_update(self._h, C.c_int(int(meas_model)), _pd(z), _pd(Q),
+                                       act.ctypes.data_as(C.POINTER(C.c_uint8)) if act is not None else None),
+                 "ukfb_update")
+        else:
+            m = np.ascontiguousarray(meas_model, dtype=np.int32).reshape(self.capacity)
+            _chk(self._lib.ukfb_update_mixed(self._h, m.ctypes.data_as(C.POINTER(C.c_int32)), _pd(z), _pd(Q)),
+                 "ukfb_update_mixed")
+
+    def update_dev(self, meas_model_uniform: int, z_dev, Q_dev, meas_model_dev=None):
+        _chk(self._lib.ukfb_update_dev(self._h, C.c_int(meas_model_uniform), _devptr(meas_model_dev), _devptr(z_dev),
+                                       _devptr(Q_dev)), "ukfb_update_dev")
+
+    # ---- fused cycle
+    def cycle(self, dt: float, meas_model: int, z, Q):
+        z = _f64(z, (self.capacity, 3)); Q = _f64(Q, (self.capacity, 3, 3))
+        _chk(self._lib.ukfb_cycle(self._h, C.c_double(dt), C.c_int(meas_model), _pd(z), _pd(Q)), "ukfb_cycle")
+
+    def cycle_dev(self, dt: float, meas_model_uniform: int, z_dev, Q_dev, meas_model_dev=None):
+        _chk(self._lib.ukfb_cycle_dev(self._h, C.c_double(dt), C.c_int(meas_model_uniform), _devptr(meas_model_dev),
+                                      _devptr(z_dev), _devptr(Q_dev)), "ukfb_cycle_dev")
+
+    # ---- measurement of the engine
+    def last_launch_info(self):
+        name = C.create_string_buffer(256)
+        lds, fpw, grid = C.c_int(0), C.c_int(0), C.c_int64(0)
+        _chk(self._lib.ukfb_last_launch_info(self._h, name, C.c_int(256), C.byref(lds), C.byref(fpw), C.byref(grid)),
+             "ukfb_last_launch_info")
+        return {"kernel": name.value.decode(), "lds_bytes": lds.value, "filters_per_workgroup": fpw.value,
+                "grid": grid.value}
+
+    def timer_begin(self):
+        _chk(self._lib.ukfb_timer_begin(self._h), "ukfb_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0)
+        _chk(self._lib.ukfb_timer_end(self._h, C.byref(ms)), "ukfb_timer_end")
+        return float(ms.value)
+
+
+class BatchPoseUKF(BatchUKF):
+    """Batched sibling of pose_estimation::PoseUKF (pose_with_velocity/PoseUKF.hpp:20-96)."""
+
+    def __init__(self, capacity: int, precision: int = F64, device: int = 0, **kw):
+        super().__init__(MODEL_POSE, precision, capacity, device, **kw)
+        # PoseUKF ctor defaults (PoseUKF.cpp:103-107)
+        self.set_process_noise(np.diag([0.01] * 3 + [0.001] * 3 + [0.00001] * 3 + [0.00001] * 3))
+
+
+class BatchOrientationUKF(BatchUKF):
+    """Batched sibling of pose_estimation::OrientationUKF (orientation_estimator/OrientationUKF.hpp:20-62)."""
+
+    EARTHW = (2.0 * np.pi) / 86164.0  # GravitationalModel.hpp:16
+
+    def __init__(self, capacity: int, gyro_bias_tau: float, acc_bias_tau: float, latitude: float,
+                 precision: int = F64, device: int = 0, **kw):
+        super().__init__(MODEL_ORIENT, precision, capacity, device, **kw)
+        # OrientationUKF.cpp:47
+        self.earth_rotation = np.array([self.EARTHW * np.cos(latitude), 0.0, self.EARTHW * np.sin(latitude)])
+        self.set_orient_params(gyro_bias_tau, acc_bias_tau, self.earth_rotation)
+
+    def initialize(self, mu, cov, first: int = 0):
+        """initializeFilter plus the ctor's input latches (OrientationUKF.cpp:49-50)."""
+        mu = _f64(mu, (-1, self.S))
+        super().initialize(mu, cov, first)
+        n = mu.shape[0]
+        acc = np.zeros((n, 3)); acc[:, 2] = mu[:, 13]
+        self.set_orient_inputs(gyro=np.zeros((n, 3)), acc=acc, first=first)

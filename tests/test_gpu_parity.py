@@ -1,0 +1,149 @@
+"""GPU parity: the HIP engine (through the C-ABI, via ctypes) against the CPU oracle on identical
+seeded inputs.  Tolerances are BASELINE.json's north_star: 1e-9 for fp64, 1e-4 for fp32 (absolute,
+max over every state and covariance entry).  PARITY UNPINNED w.r.t. real MTK: the oracle is a
+restatement (see oracle/ukf_oracle.hpp)."""
+import numpy as np
+import pytest
+
+from conftest import max_abs
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-9, 1: 1e-4}  # F64, F32
+N_SMALL = 203  # not a multiple of 4/2/1 filters per wavefront: exercises the ragged tail
+
+
+def _pose_setup(spe, n, prec, G):
+    mu, cov = spe.synth.pose_initial(n)
+    eng = spe.BatchPoseUKF(n, precision=prec, lanes_per_filter=G)
+    eng.initialize(mu, cov)
+    return eng, mu, cov
+
+
+@pytest.mark.parametrize("G", [16, 32, 64])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_pose_predict_acc_branch(spe, oracle, prec, G):
+    n = N_SMALL
+    eng, mu, cov = _pose_setup(spe, n, prec, G)
+    acc, z, Q = spe.synth.pose_cycle_inputs(n, 0, mu[:, :3])
+    acc_cov = 0.01 * np.eye(3)
+    eng.set_acceleration(acc, acc_cov)
+    eng.predict(0.01)
+    m_g, c_g, init = eng.state()
+    R = spe.synth.pose_default_process_noise()
+    m_o, c_o, st_o = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
+    assert init.all() and (eng.status() == 0).all() and (st_o == 0).all()
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    assert max_abs(m_g, mu) > 1e-4  # something happened
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_pose_predict_constant_velocity_branch(spe, oracle, prec):
+    n = N_SMALL
+    eng, mu, cov = _pose_setup(spe, n, prec, 16)
+    # half the batch has an acceleration latched, the other half keeps the NaN default (PoseUKF.cpp:109)
+    acc, _, _ = spe.synth.pose_cycle_inputs(n, 0)
+    acc[::2] = np.nan
+    eng.set_acceleration(acc, 0.02 * np.eye(3))
+    eng.predict(0.05)
+    m_g, c_g, _ = eng.state()
+    R = spe.synth.pose_default_process_noise()
+    m_o, c_o, _ = oracle.pose_predict(mu, cov, R, acc, 0.02 * np.eye(3), 0.05)
+    assert (eng.status() == 0).all()
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+
+
+@pytest.mark.parametrize("model", list(range(9)))
+@pytest.mark.parametrize("prec", [0, 1])
+def test_pose_update_each_model(spe, oracle, prec, model):
+    n = N_SMALL
+    eng, mu, cov = _pose_setup(spe, n, prec, 16)
+    _, zpos, Q = spe.synth.pose_cycle_inputs(n, 1, mu[:, :3], random_q=True)
+    z = spe.synth.pose_measurement_for_model(mu, np.full(n, model), zpos - mu[:, :3])
+    eng.update(model, z, Q)
+    m_g, c_g, _ = eng.state()
+    m_o, c_o, st_o = oracle.pose_update(mu, cov, model, z, Q)
+    assert (eng.status() == 0).all() and (st_o == 0).all()
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    assert max_abs(m_g, mu) > 1e-5
+
+
+@pytest.mark.parametrize("G", [16, 64])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_pose_fused_cycle_equals_predict_then_update(spe, oracle, prec, G):
+    n = N_SMALL
+    eng, mu, cov = _pose_setup(spe, n, prec, G)
+    acc, z, Q = spe.synth.pose_cycle_inputs(n, 0, mu[:, :3])
+    acc_cov = 0.01 * np.eye(3)
+    eng.set_acceleration(acc, acc_cov)
+    eng.cycle(0.01, spe.MEAS_POS3, z, Q)
+    m_g, c_g, _ = eng.state()
+    R = spe.synth.pose_default_process_noise()
+    m_o, c_o, _ = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
+    m_o, c_o, st = oracle.pose_update(m_o, c_o, 0, z, Q)
+    assert (eng.status() == 0).all() and (st == 0).all()
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+
+
+def test_pose_mixed_models_and_inactive_filters(spe, oracle):
+    """BASELINE config 5 shape: per-filter model ids, 25 % inactive."""
+    n = 1021
+    eng, mu, cov = _pose_setup(spe, n, 0, 16)
+    models = spe.synth.pose_mixed_models(n, 0)
+    _, zpos, Q = spe.synth.pose_cycle_inputs(n, 2, mu[:, :3], random_q=True)
+    z = spe.synth.pose_measurement_for_model(mu, models, zpos - mu[:, :3])
+    eng.update(models, z, Q)
+    m_g, c_g, _ = eng.state()
+    st_g = eng.status()
+    m_o, c_o, st_o = oracle.pose_update(mu, cov, models, z, Q)
+    assert (st_g == st_o).all()
+    assert ((st_g & spe.ST_INACTIVE) != 0).sum() == (models < 0).sum() > 0
+    assert max_abs(m_g, m_o) <= 1e-9 and max_abs(c_g, c_o) <= 1e-9
+    off = models < 0
+    assert max_abs(m_g[off], mu[off]) == 0.0 and max_abs(c_g[off], cov[off]) == 0.0
+
+
+@pytest.mark.parametrize("G", [16, 32, 64])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_orient_predict_update(spe, oracle, prec, G):
+    n = N_SMALL
+    s = spe.synth
+    mu, cov = s.orient_initial(n)
+    gyro, acc, z, Q = s.orient_cycle_inputs(n, 0, mu[:, :4])
+    eng = spe.BatchOrientationUKF(n, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE, precision=prec,
+                                  lanes_per_filter=G)
+    eng.initialize(mu, cov)
+    eng.set_process_noise(s.orient_process_noise())
+    eng.set_orient_inputs(gyro, acc)
+    eng.predict(0.01)
+    m_g, c_g, _ = eng.state()
+    m_o, c_o, st = oracle.orient_predict(mu, cov, s.orient_process_noise(), acc, gyro, s.ORIENT_TAU, s.ORIENT_TAU,
+                                         eng.earth_rotation, 0.01)
+    assert (eng.status() == 0).all() and (st == 0).all()
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    eng.update(spe.MEAS_ORIENT_BODYVEL3, z, Q)
+    m_g2, c_g2, _ = eng.state()
+    m_o2, c_o2, st2 = oracle.orient_update(m_o, c_o, z, Q)
+    assert (eng.status() == 0).all() and (st2 == 0).all()
+    assert max_abs(m_g2, m_o2) <= TOL[prec] and max_abs(c_g2, c_o2) <= TOL[prec]
+    rr = eng.rotation_rate()
+    assert max_abs(rr, oracle.orient_rotation_rate(m_g2, gyro, eng.earth_rotation)) <= 1e-12
+
+
+def test_pose_trajectory_100_cycles_fp64(spe, oracle):
+    """Config 1/2 shape on a small batch: 100 IMU-rate predict + position update cycles."""
+    n = 64
+    eng, mu, cov = _pose_setup(spe, n, 0, 16)
+    R = spe.synth.pose_default_process_noise()
+    acc_cov = 0.01 * np.eye(3)
+    m_o, c_o = mu.copy(), cov.copy()
+    for k in range(100):
+        acc, z, Q = spe.synth.pose_cycle_inputs(n, k, m_o[:, :3])
+        eng.set_acceleration(acc, acc_cov)
+        eng.cycle(0.01, spe.MEAS_POS3, z, Q)
+        m_o, c_o, s1 = oracle.pose_predict(m_o, c_o, R, acc, acc_cov, 0.01)
+        m_o, c_o, s2 = oracle.pose_update(m_o, c_o, 0, z, Q)
+        assert (s1 == 0).all() and (s2 == 0).all()
+    m_g, c_g, _ = eng.state()
+    assert eng.status_summary() == 0
+    assert max_abs(m_g, m_o) <= 1e-9 and max_abs(c_g, c_o) <= 1e-9

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- UKF predict+update filter-cycles/s on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one fused launch of PoseUKF::predictionStep(dt) on the acceleration branch followed by
+integrateMeasurement(PositionMeasurement) for EVERY filter of the batch.  The
+workload is the configuration the metric is quoted on: 1 048 576 PoseWithVelocity filters, computed in
+fp64 (the reference's own arithmetic type), sharded evenly over the N ranks (no data-path collective:
+filters are independent; RCCL is used once, after the timed region, to gather the means).  Inputs
+(acceleration, measurement, measurement covariance) are resident in HBM before the clock starts.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     -- HBM roofline of the fused kernel from ALGORITHMIC bytes
+  cpu_baseline -- the CPU oracle (a from-scratch port, kind "port") timed on this host's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TOTAL_FILTERS = 1_048_576
+DT = 0.01
+ALG_SCALARS_POSE = 2 * 157 + 15  # read+write (13 + 144) + acc 3 + z 3 + Q 9
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+class _DevArray:
+    """Zero-copy view of engine-owned device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--filters", type=int, default=TOTAL_FILTERS, help="total filters over all ranks")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-filters", type=int, default=65536)
+    ap.add_argument("--cpu-sample-cycles", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Time the oracle (reported baseline only; never the product path)."""
+    from oracle import capi
+    import slam_pose_estimation_amd as spe
+    n = args.cpu_sample_filters
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, capi.max_threads(), 16))
+    mu, cov = spe.synth.pose_initial(n)
+    R = spe.synth.pose_default_process_noise()
+    acc_cov = 0.01 * np.eye(3)
+    prec = 0 if args.precision == "f64" else 1
+    inputs = [spe.synth.pose_cycle_inputs(n, k, mu[:, :3]) for k in range(args.cpu_sample_cycles)]
+    # untimed touch
+    capi.pose_predict(mu[:64], cov[:64], R, inputs[0][0][:64], acc_cov, DT, prec=prec, threads=1)
+    t0 = time.perf_counter()
+    for acc, z, Q in inputs:
+        mu, cov, _ = capi.pose_predict(mu, cov, R, acc, acc_cov, DT, prec=prec, threads=threads)
+        mu, cov, _ = capi.pose_update(mu, cov, 0, z, Q, prec=prec, threads=threads)
+    el = time.perf_counter() - t0
+    return {"value": n * args.cpu_sample_cycles / el, "unit": "filter-cycles/s", "cores": threads, "kind": "port",
+            "sample": f"{n} PoseWithVelocity filters x {args.cpu_sample_cycles} predict(acc)+position-update cycles, "
+                      f"{args.precision}, oracle/ukf_oracle.hpp with OpenMP over filters, {el:.2f} s"}
+
+
+def load_traffic(kernel_name, filters_per_launch):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one matches this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("kernel") == kernel_name and int(t.get("filters_per_launch", -1)) == int(filters_per_launch):
+            return float(t["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import slam_pose_estimation_amd as spe
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    prec = spe.F64 if args.precision == "f64" else spe.F32
+    tdtype = torch.float64 if prec == spe.F64 else torch.float32
+    per = args.filters // world
+    first = rank * per
+    if rank == world - 1:
+        per = args.filters - first
+
+    # ---- build the shard (host generation in chunks, then resident in HBM)
+    eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
+    CH = 131072
+    n_ring = 4
+    acc_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)]
+    z_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)]
+    Q_d = [torch.empty((per, 9), dtype=tdtype, device=dev) for _ in range(n_ring)]
+    for lo in range(0, per, CH):
+        hi = min(per, lo + CH)
+        mu, cov = spe.synth.pose_initial(hi - lo, first=first + lo)
+        eng.initialize(mu, cov, first=lo)
+        for k in range(n_ring):
+            acc, z, Q = spe.synth.pose_cycle_inputs(hi - lo, k, mu[:, :3], first=first + lo)
+            acc_d[k][lo:hi] = torch.from_numpy(acc).to(dev, tdtype)
+            z_d[k][lo:hi] = torch.from_numpy(z).to(dev, tdtype)
+            Q_d[k][lo:hi] = torch.from_numpy(Q.reshape(-1, 9)).to(dev, tdtype)
+    eng.set_acceleration(None, 0.01 * np.eye(3))
+    torch.cuda.synchronize()
+
+    def step(k):
+        r = k % n_ring
+        eng.bind_acceleration_dev(acc_d[r])
+        eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r])
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    eng.timer_begin()           # HIP events on the stream the kernel is launched on
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    kernel_ms_total = eng.timer_end()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status_or = eng.status_summary()
+
+    # ---- result gather over RCCL/xGMI (outside the timed region; means only)
+    gather_ms = None
+    if dist is not None:
+        mu_ptr, _, _ = eng.device_views()
+        mu_local = torch.as_tensor(_DevArray(mu_ptr, (per, 13), "<f8" if prec == spe.F64 else "<f4"), device=dev)
+        if per * world == args.filters:
+            out = torch.empty((args.filters, 13), dtype=tdtype, device=dev)
+            fence()
+            g0 = time.perf_counter()
+            dist.all_gather_into_tensor(out, mu_local)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+
+    info = eng.last_launch_info()
+    if rank == 0:
+        tsize = 8 if prec == spe.F64 else 4
+        value = args.filters * args.steps / elapsed
+        alg_bytes_launch = ALG_SCALARS_POSE * tsize * per
+        kernel_ms = kernel_ms_total / args.steps
+        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "UKF predict+update filter-cycles/s, PoseWithVelocity filters",
+            "value": value,
+            "unit": "filter-cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"{args.filters} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)"
+                                   f"+PositionMeasurement update per step, {args.precision}, "
+                                   f"{per} filters per GPU", "filters": args.filters, "filters_per_gpu": per,
+                       "lanes_per_filter": 64 // max(1, info["filters_per_workgroup"]),
+                       "parallelism": f"filter-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_traffic(info["kernel"], per),
+                         "kernel": info["kernel"], "kernel_ms_per_launch": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "lds_bytes_per_workgroup": info["lds_bytes"]},
+            "status_or": status_or,
+            "gather_ms": gather_ms,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

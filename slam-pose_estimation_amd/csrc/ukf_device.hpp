@@ -42,6 +42,168 @@ UKFB_DEV bool m_finite(float x) { return isfinite(x); }
 
 enum { QX = 0, QY = 1, QZ = 2, QW = 3 };
 
+// ---------------------------------------------------------------------------------------------
+// Fast, division-free primitives for the tuned kernel (ukf_kernel16.hpp).  All are accurate to a
+// few ulp of T, far inside the 1e-9 (f64) / 1e-4 (f32) parity budget, and replace the ocml
+// sqrt / sincos / atan / IEEE-division expansions that dominated the first kernel's VALU time.
+// ---------------------------------------------------------------------------------------------
+// 1/sqrt(x): v_rsq + Goldschmidt refinement (two steps f64, one step f32).
+UKFB_DEV double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    double y = x * r, h = 0.5 * r;
+    double e = fma(-h, y, 0.5);
+    y = fma(y, e, y);
+    h = fma(h, e, h);
+    e = fma(-h, y, 0.5);
+    h = fma(h, e, h);
+    return h + h;
+}
+UKFB_DEV float fast_rsqrt(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    const float e = fmaf(-x * r, r, 1.0f);
+    return fmaf(0.5f * r, e, r);
+}
+// 1/x: v_rcp + Newton (two steps f64, one step f32).
+UKFB_DEV double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+UKFB_DEV float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
+template <class T> struct Poly;
+template <> struct Poly<double> {
+    // cos(sqrt(y)) = sum (-1)^k y^k/(2k)!, sinc(sqrt(y)) = sum (-1)^k y^k/(2k+1)!  (|y| <= 0.62: < 1 ulp)
+    static UKFB_DEV void cos_sinc(double y, double& c, double& s) {
+        double pc = 1.0 / 121645100408832000.0;   // 1/19! (sinc k=9)
+        double qc = -1.0 / 6402373705728000.0;    // -1/18! (cos k=9)
+        qc = fma(qc, y, 1.0 / 20922789888000.0);      pc = fma(-pc, y, 1.0 / 355687428096000.0);   // 1/16!, 1/17!
+        qc = fma(qc, y, -1.0 / 87178291200.0);        pc = fma(pc, y, -1.0 / 1307674368000.0);     // -1/14!, -1/15!
+        qc = fma(qc, y, 1.0 / 479001600.0);           pc = fma(pc, y, 1.0 / 6227020800.0);         // 1/12!, 1/13!
+        qc = fma(qc, y, -1.0 / 3628800.0);            pc = fma(pc, y, -1.0 / 39916800.0);          // -1/10!, -1/11!
+        qc = fma(qc, y, 1.0 / 40320.0);               pc = fma(pc, y, 1.0 / 362880.0);             // 1/8!, 1/9!
+        qc = fma(qc, y, -1.0 / 720.0);                pc = fma(pc, y, -1.0 / 5040.0);              // -1/6!, -1/7!
+        qc = fma(qc, y, 1.0 / 24.0);                  pc = fma(pc, y, 1.0 / 120.0);                // 1/4!, 1/5!
+        qc = fma(qc, y, -0.5);                        pc = fma(pc, y, -1.0 / 6.0);                 // -1/2!, -1/3!
+        c = fma(qc, y, 1.0);
+        s = fma(pc, y, 1.0);
+    }
+    // atan(sqrt(u))/sqrt(u) = sum (-1)^k u^k/(2k+1), 0 <= u <= 0.07 (14 terms; even/odd split)
+    static UKFB_DEV double atan_ratio(double u) {
+        const double u2 = u * u;
+        double e = 1.0 / 25.0, o = -1.0 / 27.0;
+        e = fma(e, u2, 1.0 / 21.0);  o = fma(o, u2, -1.0 / 23.0);
+        e = fma(e, u2, 1.0 / 17.0);  o = fma(o, u2, -1.0 / 19.0);
+        e = fma(e, u2, 1.0 / 13.0);  o = fma(o, u2, -1.0 / 15.0);
+        e = fma(e, u2, 1.0 / 9.0);   o = fma(o, u2, -1.0 / 11.0);
+        e = fma(e, u2, 1.0 / 5.0);   o = fma(o, u2, -1.0 / 7.0);
+        e = fma(e, u2, 1.0);         o = fma(o, u2, -1.0 / 3.0);
+        return fma(o, u, e);
+    }
+    static constexpr double Y_SMALL = 0.62, U_SMALL = 0.07;
+};
+template <> struct Poly<float> {
+    static UKFB_DEV void cos_sinc(float y, float& c, float& s) {
+        float qc = 1.0f / 479001600.0f, pc = 1.0f / 6227020800.0f;   // 1/12!, 1/13!
+        qc = fmaf(qc, y, -1.0f / 3628800.0f);   pc = fmaf(pc, y, -1.0f / 39916800.0f);
+        qc = fmaf(qc, y, 1.0f / 40320.0f);      pc = fmaf(pc, y, 1.0f / 362880.0f);
+        qc = fmaf(qc, y, -1.0f / 720.0f);       pc = fmaf(pc, y, -1.0f / 5040.0f);
+        qc = fmaf(qc, y, 1.0f / 24.0f);         pc = fmaf(pc, y, 1.0f / 120.0f);
+        qc = fmaf(qc, y, -0.5f);                pc = fmaf(pc, y, -1.0f / 6.0f);
+        c = fmaf(qc, y, 1.0f);
+        s = fmaf(pc, y, 1.0f);
+    }
+    static UKFB_DEV float atan_ratio(float u) {
+        const float u2 = u * u;
+        float e = 1.0f / 13.0f, o = -1.0f / 15.0f;
+        e = fmaf(e, u2, 1.0f / 9.0f);   o = fmaf(o, u2, -1.0f / 11.0f);
+        e = fmaf(e, u2, 1.0f / 5.0f);   o = fmaf(o, u2, -1.0f / 7.0f);
+        e = fmaf(e, u2, 1.0f);          o = fmaf(o, u2, -1.0f / 3.0f);
+        return fmaf(o, u, e);
+    }
+    static constexpr float Y_SMALL = 0.62f, U_SMALL = 0.07f;
+};
+
+template <class T> struct TwoPi;
+template <> struct TwoPi<double> {
+    static constexpr double hi = 6.283185307179586, lo = 2.4492935982947064e-16, inv = 0.15915494309189535;
+};
+template <> struct TwoPi<float> {
+    static constexpr float hi = 6.28318548f, lo = -1.74845553e-07f, inv = 0.159154937f;
+};
+UKFB_DEV double m_rint(double x) { return __builtin_rint(x); }
+UKFB_DEV float m_rint(float x) { return __builtin_rintf(x); }
+UKFB_DEV double m_abs(double x) { return __builtin_fabs(x); }
+UKFB_DEV float m_abs(float x) { return __builtin_fabsf(x); }
+
+// (cos(sqrt(y)), sin(sqrt(y))/sqrt(y)) for y >= 0 with no sqrt / sincos / division on the common path:
+// Taylor polynomial in y up to (pi/4)^2; one angle doubling up to (pi/2)^2; beyond that the angle is
+// reduced modulo 2 pi (two-term Cody-Waite, wave-uniform branch) and doubled twice.  No ocml calls:
+// their inlined large-argument paths cost ~100 live registers per call site.
+template <class T> UKFB_DEV void cos_sinc_fast(T y, T& c, T& s) {
+    const bool small = y <= Poly<T>::Y_SMALL;
+    const bool big = !(y <= T(4) * Poly<T>::Y_SMALL);
+    T yy = small ? y : T(0.25) * y;
+    T ratio = T(1);
+    if (__any(big)) {
+        const T rs = fast_rsqrt(big ? y : T(1));         // 1/x
+        const T x = y * rs;
+        const T k = m_rint(x * TwoPi<T>::inv);
+        T xr = fma(-k, TwoPi<T>::hi, x);
+        xr = fma(-k, TwoPi<T>::lo, xr);                  // |xr| <= pi
+        yy = big ? (xr * xr) * T(0.0625) : yy;           // (xr/4)^2 <= (pi/4)^2
+        ratio = big ? xr * rs : T(1);                    // sin(x)/x = sinc(xr) * xr/x
+    }
+    T c1, s1;
+    Poly<T>::cos_sinc(yy, c1, s1);
+    const T c2 = fma(T(2) * c1, c1, T(-1)), s2 = s1 * c1;    // angle x2
+    const T c4 = fma(T(2) * c2, c2, T(-1)), s4 = s2 * c2;    // angle x4
+    c = small ? c1 : (big ? c4 : c2);
+    s = small ? s1 : (big ? s4 * ratio : s2);
+}
+
+// exp / log with the fast primitives (same maps as so3_exp / so3_log below)
+template <class T> UKFB_DEV void so3_exp_fast(const T (&v)[3], T scale, T (&q)[4]) {
+    const T s = scale * T(0.5);
+    const T n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    T c, sc;
+    cos_sinc_fast(s * s * n2, c, sc);
+    const T mult = sc * s;
+    q[0] = mult * v[0]; q[1] = mult * v[1]; q[2] = mult * v[2]; q[3] = c;
+}
+// 2 atan(|vec|/w)/|vec| * vec = (2/w) * [atan(t)/t] * vec with t^2 = |vec|^2 / w^2.  Beyond ~30 degrees
+// (wave-uniform branch) the half angle phi = atan(|vec|/|w|) is halved three times with
+// tan(phi/2) = t / (1 + sqrt(1 + t^2)), which brings it below atan(0.2); sign of w restores MTK's
+// plus/minus periodicity.  No ocml calls.
+template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
+    const T v2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const T w = q[3];
+    const T rw = fast_rcp(w);
+    const T u = v2 * rw * rw;
+    T s = T(2) * rw * Poly<T>::atan_ratio(u);
+    const bool big = !(u <= Poly<T>::U_SMALL);
+    if (__any(big)) {
+        const T n2 = fma(w, w, v2);
+        const T n = n2 * fast_rsqrt(n2);
+        const T r1 = fast_rcp(m_abs(w) + n);
+        const T t1 = v2 * r1 * r1;                       // tan^2(phi/2) <= 1
+        const T q2 = T(1) + t1;
+        const T r2 = fast_rcp(T(1) + q2 * fast_rsqrt(q2));
+        const T t2 = t1 * r2 * r2;                       // tan^2(phi/4) <= 0.172
+        const T q3 = T(1) + t2;
+        const T r3 = fast_rcp(T(1) + q3 * fast_rsqrt(q3));
+        const T t3 = t2 * r3 * r3;                       // tan^2(phi/8) <= 0.0396
+        const T sb = T(16) * (r1 * r2) * r3 * Poly<T>::atan_ratio(t3);
+        s = big ? ((w < T(0)) ? -sb : sb) : s;
+    }
+    r[0] = s * q[0]; r[1] = s * q[1]; r[2] = s * q[2];
+}
+
+
 // MTK cos_sinc_sqrt: (cos(sqrt(x2)), sin(sqrt(x2))/sqrt(x2)), three Taylor pairs below eps^(1/4).
 template <class T> UKFB_DEV void cos_sinc_sqrt(T x2, T& c, T& s) {
     T cosi = T(1), sinc = T(1);
@@ -267,7 +429,8 @@ template <class T> struct OrientM {
     // velocityMeasurementModel (OrientationUKF.cpp:34-39): q.inverse() * v
     static UKFB_DEV void measure(const T (&x)[14], int, T (&z)[4]) {
         const T n2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-        const T qi[4] = {-x[0] / n2, -x[1] / n2, -x[2] / n2, x[3] / n2};
+        const T rn = fast_rcp(n2);
+        const T qi[4] = {-x[0] * rn, -x[1] * rn, -x[2] * rn, x[3] * rn};
         const T v[3] = {x[4], x[5], x[6]};
         T r[3];
         quat_rotate(qi, v, r);

@@ -87,7 +87,11 @@ template <class T, class M> struct Layout {
 
 template <class T, class M> constexpr int lds_bytes_per_filter() { return Layout<T, M>::PF * int(sizeof(T)); }
 
-UKFB_DEV void wsync() { __syncthreads(); }  // one wavefront per workgroup: no s_barrier wait across waves
+UKFB_DEV void wsync() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}  // one wavefront per workgroup: no s_barrier wait across waves
 
 template <int G> UKFB_DEV double gshfl(double v, int src) { return __shfl(v, src, G); }
 template <int G> UKFB_DEV float gshfl(float v, int src) { return __shfl(v, src, G); }

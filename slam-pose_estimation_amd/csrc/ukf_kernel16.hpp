@@ -1,0 +1,879 @@
+// ukf_kernel16.hpp -- tuned fused UKF kernel: one DPP row (16 lanes) per filter, 4 filters per
+// wavefront, one wavefront per workgroup (gfx950 / MI355X).
+//
+// Same arithmetic contract as ukf_kernel.hpp (ukfom predict / update as reached from
+// PoseUKF.cpp:114-172,192,195 and OrientationUKF.cpp:69,88), re-organised after profiling the
+// first kernel (profiles/r01_base_*): it was VALU-issue and LDS-latency bound, not HBM bound.
+//
+//  * lane l < D owns the sigma PAIR mu [+] (+L col l), mu [+] (-L col l): one L column read and one
+//    SO(3) exp serve both points (exp(-v) = conj(exp(v))); lane D owns the centre point.
+//  * manifold means are reduced with a 4-step DPP butterfly (quad_perm, quad_perm, row_half_mirror,
+//    row_mirror) -- no LDS round trip, bit-identical totals on all 16 lanes.  Euclidean components
+//    converge in the first iteration, so later iterations only touch the SO(3) part.
+//  * Cholesky: rows in VGPRs, ONE LDS hop per column (unscaled column + pivot published together,
+//    every lane derives rsqrt(pivot) itself); consumers scale columns on the fly.
+//  * covariance recombination 0.5 * sum d d^T is blocked into 16 register tiles (2x3 for D = 12,
+//    3x3 for D = 13) reading the delta table from LDS.
+//  * the update exploits exact identities of the unscented transform instead of recomputing them:
+//    (mu [+] d) [-] mu = d for the state deltas, and in applyDelta the Euclidean block of
+//    0.5 sum (X_i [-] X_0)(..)^T equals L' L'^T = Sigma' entry for entry, so only the rows/columns
+//    of the SO(3) component are re-sampled (through exp/log).  Results differ from the literal
+//    restatement by rounding only (tests/test_gpu_parity.py holds both to 1e-9 / 1e-4).
+//  * LDS per filter: delta table (aliases the factor and the packed-covariance staging) + 112
+//    scalars; 12.9 KB per wavefront in fp64 -> 3 wavefronts per SIMD.
+//
+// TOOLCHAIN NOTE (ROCm 7.2 hipcc, -O2/-O3): when this kernel needed VGPR spills / live-range
+// splits, the compiler placed the copies at the join label of a divergent `if` BEFORE the
+// `s_or_b64 exec` restore; entered through `s_cbranch_execz` (EXEC = 0) they save nothing and the
+// reload returns stale registers.  The kernel is therefore written to need no spills (checked by
+// the build: scratch = 0, AGPR = 0) and with as few exec-masked regions as possible: lane-predicated
+// LDS stores select a dummy address instead of branching, rare math fall-backs are wave-uniform.
+#pragma once
+
+#include "ukf_kernel.hpp"
+
+namespace ukfb {
+
+// ---------------------------------------------------------------------------------------------
+// DPP row (16 lanes) all-reduce
+// ---------------------------------------------------------------------------------------------
+template <int CTRL> UKFB_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> UKFB_DEV double dpp_mov(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, int(unsigned(b)), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, int(unsigned(b >> 32)), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32));
+}
+// xor-1, xor-2 inside quads, then mirrored halves: every lane of the row ends with the same bits.
+template <class T> UKFB_DEV T row_allreduce(T v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// manifold traits for the tuned kernel
+// ---------------------------------------------------------------------------------------------
+template <class M> struct MT;
+template <class T> struct MT<PoseM<T>> {
+    static constexpr int Q = 3;    // stored offset of the quaternion
+    static constexpr int RT = 3;   // tangent offset of the rotation
+    static constexpr int TR = 2, TC = 3;  // covariance tile
+};
+template <class T> struct MT<OrientM<T>> {
+    static constexpr int Q = 0, RT = 0, TR = 3, TC = 3;
+};
+
+template <class T, class M> struct Layout16 {
+    static constexpr int VEC = 16 / int(sizeof(T));
+    static constexpr int D = M::D, S = M::S, N = 2 * D + 1, PK = D * (D + 1) / 2;
+    static constexpr int LS = (D + VEC - 1) / VEC * VEC;   // column stride of the factor = row stride of the deltas
+    static constexpr int PKP = (PK + VEC - 1) / VEC * VEC;
+    static constexpr int LC = 0;                            // D*LS : unscaled factor columns
+    static constexpr int DXT = 0;                           // N*LS : delta table (aliases LC and PKS)
+    static constexpr int PKS = D * LS;                      // PKP  : packed covariance staging
+    static constexpr int MISC = N * LS;
+    static constexpr int MUS = MISC;                        // 16 : mean staging
+    static constexpr int ROT = MISC + 16;                   // 12 : rotation matrix of the mean
+    static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
+    static constexpr int WK = MISC + 40;                    // D*4 (<= 56): W / K / cross-term exchange
+    static constexpr int DUM = MISC + 96;                   // 16 : sink for lane-predicated stores
+    static constexpr int PF = MISC + 112;
+    static_assert(D * LS + PKP <= N * LS, "packed staging must fit behind the factor");
+    static_assert(D * 4 <= 56 && PF % VEC == 0 && LS <= 16 && S <= 16, "scratch layout");
+};
+
+template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layout16<T, M>::PF * int(sizeof(T)); }
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky: lane l < D holds row l (entries 0..l) in a[].  Column k is published UNSCALED
+// (v_l = a_l[k], pivot included) with one LDS write; every lane reads pivot + the column entries it
+// needs, derives rs = 1/sqrt(pivot) itself and updates its trailing row.  L[c][k] = Lc[k*LS+c]*rs_k
+// for c >= k (entries above the diagonal are garbage and must be masked by the consumer).
+// Returns this lane's rs_l (lane l < D); ok = all pivots > 0.  `dum`: offset of the store sink.
+// ---------------------------------------------------------------------------------------------
+// scheduling fence: keeps the machine scheduler from hoisting the next phase's loads / ALU work
+// across this point (it otherwise trades ~2x the registers for ILP and ends up spilling)
+UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
+
+template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
+    T my_rs = T(0);
+    bool good = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        Lc[(l < D) ? (k * LS + l) : dum] = a[k];
+        wsync();
+        const T akk = Lc[k * LS + k];
+        good = good && (akk > T(0));
+        const T rs = fast_rsqrt(akk);
+        my_rs = (l == k) ? rs : my_rs;
+        const T t = a[k] * (rs * rs);
+#pragma unroll
+        for (int c = k + 1; c < D; ++c) a[c] = fma(-t, Lc[k * LS + c], a[c]);
+        sfence();
+    }
+    ok = good;
+    return my_rs;
+}
+
+// row l of a packed lower-triangular matrix (zeros beyond the diagonal / for lanes >= D)
+template <class T, int D> UKFB_DEV void load_row(const T* PKS, int l, T (&row)[D]) {
+    const int lr = (l < D) ? l : (D - 1);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const T v = PKS[lr * (lr + 1) / 2 + ((j <= lr) ? j : 0)];
+        row[j] = (l < D && j <= l) ? v : T(0);
+    }
+}
+
+// scaled column l of the factor (zeros above the diagonal)
+template <class T, int D, int LS> UKFB_DEV void load_column(const T* Lc, int l, T rs, T (&col)[D]) {
+    const int lc = (l < D) ? l : (D - 1);
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const T v = Lc[lc * LS + c] * rs;
+        col[c] = (c >= l) ? v : T(0);
+    }
+}
+
+// fast boxminus of the SO(3) component only: log(conj(y) * x)
+template <class T> UKFB_DEV void rot_minus(const T (&qx)[4], const T (&qy)[4], T (&r)[3]) {
+    const T oc[4] = {-qy[0], -qy[1], -qy[2], qy[3]};
+    T d[4];
+    quat_mul(oc, qx, d);
+    so3_log_fast(d, r);
+}
+
+// process models with the fast exp (same statements as PoseM/OrientM::process)
+template <class T> UKFB_DEV void process_fast(PoseM<T>*, T (&x)[13], const ProcIn<T>& in) {
+    x[7] += in.use_acc ? in.dt * in.a[0] : T(0);
+    x[8] += in.use_acc ? in.dt * in.a[1] : T(0);
+    x[9] += in.use_acc ? in.dt * in.a[2] : T(0);
+    T q[4] = {x[3], x[4], x[5], x[6]};
+    const T v[3] = {x[7], x[8], x[9]}, w[3] = {x[10], x[11], x[12]};
+    T rv[3], rw[3], e[4], r[4];
+    quat_rotate(q, v, rv);
+    x[0] += in.dt * rv[0]; x[1] += in.dt * rv[1]; x[2] += in.dt * rv[2];
+    quat_rotate(q, w, rw);
+    so3_exp_fast(rw, in.dt, e);
+    quat_mul(q, e, r);
+    x[3] = r[0]; x[4] = r[1]; x[5] = r[2]; x[6] = r[3];
+}
+template <class T> UKFB_DEV void process_fast(OrientM<T>*, T (&x)[14], const ProcIn<T>& in) {
+    T q[4] = {x[0], x[1], x[2], x[3]};
+    const T t[3] = {in.w[0] - x[7], in.w[1] - x[8], in.w[2] - x[9]};
+    T av[3], e[4], r[4];
+    quat_rotate(q, t, av);
+    av[0] -= in.earth[0]; av[1] -= in.earth[1]; av[2] -= in.earth[2];
+    so3_exp_fast(av, in.dt, e);
+    quat_mul(q, e, r);
+    x[0] = r[0]; x[1] = r[1]; x[2] = r[2]; x[3] = r[3];
+    const T u[3] = {in.a[0] - x[10], in.a[1] - x[11], in.a[2] - x[12]};
+    T acc[3];
+    quat_rotate(r, u, acc);
+    acc[2] -= x[13];
+    x[4] += in.dt * acc[0]; x[5] += in.dt * acc[1]; x[6] += in.dt * acc[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        x[7 + k] += in.dt * (in.ninv_tau_g * x[7 + k]);
+        x[10 + k] += in.dt * (in.ninv_tau_a * x[10 + k]);
+    }
+}
+
+// sigma pair mu [+] (+col), mu [+] (-col).  need_q = false skips the SO(3) part (measurement models
+// that do not read the orientation).
+template <class T, class M>
+UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], bool need_q, T (&xp)[M::S], T (&xm)[M::S]) {
+    constexpr int Q = MT<M>::Q, RT = MT<M>::RT, S = M::S;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s < Q) { xp[s] = mu[s] + col[s]; xm[s] = mu[s] - col[s]; }
+        else if (s >= Q + 4) { xp[s] = mu[s] + col[s - 1]; xm[s] = mu[s] - col[s - 1]; }
+        else { xp[s] = mu[s]; xm[s] = mu[s]; }
+    }
+    if (need_q) {   // wave-uniform
+        const T q[4] = {mu[Q], mu[Q + 1], mu[Q + 2], mu[Q + 3]};
+        const T v[3] = {col[RT], col[RT + 1], col[RT + 2]};
+        T ep[4], rp[4], rm[4];
+        so3_exp_fast(v, T(1), ep);
+        const T em[4] = {-ep[0], -ep[1], -ep[2], ep[3]};
+        quat_mul(q, ep, rp);
+        quat_mul(q, em, rm);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xp[Q + k] = rp[k]; xm[Q + k] = rm[k]; }
+    }
+}
+
+// One entry of the shaped process noise R without exec-masked regions (cf. process_noise_entry).
+template <class T, class M>
+UKFB_DEV T process_noise_entry16(const T* Rn, const T* ROT, const KArgs<T>& a, const ProcIn<T>& pin, int r, int c) {
+    constexpr int D = M::D;
+    const T rn = Rn[r * D + c];
+    T vacc = rn;
+    if (M::MODEL == 0) {
+        // acceleration branch (PoseUKF.cpp:190-191): raw noise, block(6,6,3,3) = 2 acc.cov
+        const bool vel = (r >= 6 && r < 9 && c >= 6 && c < 9);
+        const int k = vel ? ((r - 6) * 3 + (c - 6)) : 0;
+        T ac = T(0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) ac = (k == s) ? a.acc_cov[s] : ac;
+        vacc = vel ? T(2) * ac : rn;
+        if (__all(pin.use_acc)) return vacc;   // wave-uniform fast path
+    }
+    const int o = (r < 3 && c < 3) ? 0 : ((r >= 3 && r < 6 && c >= 3 && c < 6) ? 3 : -1);
+    const int oo = o < 0 ? 0 : o;
+    const int rr = (o < 0) ? 0 : (r - oo), cc = (o < 0) ? 0 : (c - oo);
+    T acc = T(0);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        T tmp = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tmp += ROT[rr * 3 + k] * Rn[(oo + k) * D + (oo + m)];
+        acc += tmp * ROT[cc * 3 + m];
+    }
+    const T val = (o >= 0) ? acc : rn;
+    const T scale = (M::MODEL == 0) ? pin.dt : pin.dt * pin.dt;
+    const T vcv = scale * val;
+    return (M::MODEL == 0 && pin.use_acc) ? vacc : vcv;
+}
+
+// minimum waves per SIMD for the register allocator (LDS admits 3 in fp64, 6 in fp32)
+#ifndef UKFB_W64
+#define UKFB_W64 2
+#endif
+#ifndef UKFB_W32
+#define UKFB_W32 4
+#endif
+template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W64 : UKFB_W32; }
+
+template <class T, class M, bool DO_PREDICT, bool DO_UPDATE>
+__global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
+    constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
+    using LY = Layout16<T, M>;
+    constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
+    constexpr int G = 16, FPW = 4, EPL = (PK + G - 1) / G;
+    static_assert(D + 1 <= G && S <= G, "a filter must fit one DPP row");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const int64_t f = int64_t(blockIdx.x) * FPW + g;
+    const bool fvalid = f < a.n;
+    const int64_t fc = fvalid ? f : (a.n - 1);
+    T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
+    T* Lc = base + LY::LC;
+    T* DXT = base + LY::DXT;
+    T* PKS = base + LY::PKS;
+    T* MUS = base + LY::MUS;
+    T* ROT = base + LY::ROT;
+    T* ZQ = base + LY::ZQ;
+    T* WK = base + LY::WK;
+    T* DUMP = base + LY::DUM;
+    const bool has_pair = l < D;       // lane owns the sigma pair of column l
+    const bool has_ctr = l == D;       // lane owns the centre point
+
+    uint32_t st = ST_OK;
+    const bool live = fvalid && (a.initialised[fc] != 0);
+    st |= (fvalid && !live) ? ST_UNINITIALISED : 0u;
+
+    // ---- time gate (UnscentedKalmanFilter.hpp:83-125)
+    bool do_p = false, p_error = false;
+    T dtT = T(0);
+    if constexpr (DO_PREDICT) {
+        double dt;
+        bool first = false;
+        if (a.ts) {   // uniform
+            const int64_t last = a.last_ts[fc], ts = a.ts[fc];
+            first = (last == 0);
+            dt = first ? 0.0 : double(ts - last) / 1000000.0;
+            if (live && l == 0 && (first || dt > a.min_dt)) a.last_ts[fc] = ts;
+        } else {
+            dt = a.dt ? a.dt[fc] : a.dt_uniform;
+        }
+        const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
+        const uint32_t code = first ? ST_SKIPPED_FIRST_TS
+                                    : (neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u)));
+        st |= live ? code : 0u;
+        p_error = live && !first && (neg || (!small && large));
+        do_p = live && code == 0u;
+        dtT = T(dt);
+    }
+    bool do_u = false;
+    int mid = -1;
+    if constexpr (DO_UPDATE) {
+        mid = a.meas ? a.meas[fc] : a.meas_uniform;
+        const bool act = M::meas_valid(mid) && (a.active ? a.active[fc] != 0 : true);
+        do_u = live && act && !p_error;
+        st |= (live && !do_u) ? ST_INACTIVE : 0u;
+    }
+
+    // ---- stage the filter: packed covariance and mean -> LDS
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int e = l + G * t;
+        const T v = a.cov[fc * PK + ((e < PK) ? e : (PK - 1))];
+        PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = v;
+    }
+    {
+        const T v = a.mu[fc * S + ((l < S) ? l : (S - 1))];
+        MUS[(l < S) ? l : (LY::DUM - LY::MUS)] = v;
+    }
+    wsync();
+
+    bool p_commit = false, u_commit = false;
+
+    // =========================================================================== predict
+    if constexpr (DO_PREDICT) {
+        if (__any(do_p)) {
+            ProcIn<T> pin;
+            pin.dt = dtT;
+            pin.ninv_tau_g = a.ninv_tau_g;
+            pin.ninv_tau_a = a.ninv_tau_a;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pin.earth[k] = a.earth[k];
+                pin.a[k] = a.in_a ? a.in_a[fc * 3 + k] : T(NAN);
+                pin.w[k] = a.in_b ? a.in_b[fc * 3 + k] : T(0);
+            }
+            pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
+
+            T xp[S], xm[S], ref[S];
+            bool ok;
+            {
+                T mu_r[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
+                {   // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81)
+                    T q[4], rot[9];
+                    M::orientation(mu_r, q);
+                    quat_to_matrix(q, rot);
+                    T* dst = (l == 0) ? ROT : DUMP;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dst[k] = rot[k];
+                }
+                T rs;
+                {
+                    T arow[D];
+                    load_row<T, D>(PKS, l, arow);
+                    rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, ok);
+                    wsync();
+                }
+                T col[D];
+                load_column<T, D, LS>(Lc, l, rs, col);
+                sigma_pair<T, M>(mu_r, col, true, xp, xm);
+#pragma unroll
+                for (int s = 0; s < S; ++s) ref[s] = mu_r[s];
+            }
+            const bool pc = do_p && ok;            // this filter's predict will be committed
+            sfence();
+            process_fast((M*)nullptr, ref, pin);   // centre point, carried by every lane
+            sfence();
+            process_fast((M*)nullptr, xp, pin);
+            sfence();
+            process_fast((M*)nullptr, xm, pin);
+            sfence();
+#pragma unroll
+            for (int s = 0; s < S; ++s) xp[s] = has_ctr ? ref[s] : xp[s];
+            const bool has_p = has_pair || has_ctr, has_m = has_pair;
+
+            // ---- ukfom meanSigmaPoints, first iteration over the whole tangent (reference = centre)
+            sfence();
+            T n2 = T(0);
+            {
+                T loc[D];
+                {
+                    const T qr[4] = {ref[Q], ref[Q + 1], ref[Q + 2], ref[Q + 3]};
+                    const T qp[4] = {xp[Q], xp[Q + 1], xp[Q + 2], xp[Q + 3]};
+                    const T qm[4] = {xm[Q], xm[Q + 1], xm[Q + 2], xm[Q + 3]};
+                    T rp[3], rm[3];
+                    rot_minus(qp, qr, rp);
+                    rot_minus(qm, qr, rm);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) loc[RT + k] = (has_p ? rp[k] : T(0)) + (has_m ? rm[k] : T(0));
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s < Q) loc[s] = (has_p ? xp[s] - ref[s] : T(0)) + (has_m ? xm[s] - ref[s] : T(0));
+                    else if (s >= Q + 4) loc[s - 1] = (has_p ? xp[s] - ref[s] : T(0)) + (has_m ? xm[s] - ref[s] : T(0));
+                }
+                T md[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    md[c] = row_allreduce(loc[c]) * (T(1) / T(N));
+                    n2 += md[c] * md[c];
+                }
+                // reference [+] mean delta
+                {
+                    const T qr[4] = {ref[Q], ref[Q + 1], ref[Q + 2], ref[Q + 3]};
+                    const T v[3] = {md[RT], md[RT + 1], md[RT + 2]};
+                    T e[4], r[4];
+                    so3_exp_fast(v, T(1), e);
+                    quat_mul(qr, e, r);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (s < Q) ref[s] += md[s];
+                        else if (s >= Q + 4) ref[s] += md[s - 1];
+                        else ref[s] = r[s - Q];
+                    }
+                }
+            }
+            // Euclidean part of the mean is final: write those delta columns now and drop the registers
+            wsync();  // every lane is done with the factor columns (they alias the table)
+            {
+                T* rowp = has_p ? (DXT + (has_ctr ? (2 * D) : (2 * l)) * LS) : DUMP;
+                T* rowm = has_m ? (DXT + (2 * l + 1) * LS) : DUMP;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s < Q) { rowp[s] = xp[s] - ref[s]; rowm[s] = xm[s] - ref[s]; }
+                    else if (s >= Q + 4) { rowp[s - 1] = xp[s] - ref[s]; rowm[s - 1] = xm[s] - ref[s]; }
+                }
+            }
+            {   // mean staging: Euclidean part now, quaternion after the loop (lane 0)
+                T* dst = (pc && l == 0) ? MUS : DUMP;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    if (s < Q || s >= Q + 4) dst[s] = ref[s];
+            }
+            sfence();
+            // ---- remaining iterations: SO(3) component only
+            T qr[4] = {ref[Q], ref[Q + 1], ref[Q + 2], ref[Q + 3]};
+            const T qp[4] = {xp[Q], xp[Q + 1], xp[Q + 2], xp[Q + 3]};
+            const T qm[4] = {xm[Q], xm[Q + 1], xm[Q + 2], xm[Q + 3]};
+            bool conv = true;
+            {
+                bool active = n2 > a.mean_tol * a.mean_tol;
+                int it = 0;
+                if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
+#ifdef X_NO_LOOP
+                while (false) {
+#else
+                while (__any(active)) {
+#endif
+                    T rp[3], rm[3], mr[3];
+                    rot_minus(qp, qr, rp);
+                    rot_minus(qm, qr, rm);
+                    T m2 = T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T loc = (has_p ? rp[k] : T(0)) + (has_m ? rm[k] : T(0));
+                        mr[k] = row_allreduce(loc) * (T(1) / T(N));
+                        m2 += mr[k] * mr[k];
+                    }
+                    T e[4], nq[4];
+                    so3_exp_fast(mr, T(1), e);
+                    quat_mul(qr, e, nq);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) qr[k] = active ? nq[k] : qr[k];
+                    const bool more = m2 > a.mean_tol * a.mean_tol;
+                    const bool capped = more && (it + 1 >= a.mean_max_it);
+                    it += (active && more) ? 1 : 0;
+                    conv = conv && !(active && capped);
+                    active = active && more && !capped;
+                }
+            }
+            {   // rotation deltas to the final mean; quaternion of the mean
+                T rp[3], rm[3];
+                rot_minus(qp, qr, rp);
+                rot_minus(qm, qr, rm);
+                T* rowp = has_p ? (DXT + (has_ctr ? (2 * D) : (2 * l)) * LS) : DUMP;
+                T* rowm = has_m ? (DXT + (2 * l + 1) * LS) : DUMP;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { rowp[RT + k] = rp[k]; rowm[RT + k] = rm[k]; }
+                T* dst = (pc && l == 0) ? MUS : DUMP;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[Q + k] = qr[k];
+            }
+            wsync();
+            // ---- covariance tiles: lane -> (r0, c0) of a TR x TC block with c0 <= r0 + TR - 1
+            int r0 = -1, c0 = 0;
+            {
+                int cnt = 0;
+#pragma unroll
+                for (int p = 0; p < (D + TR - 1) / TR; ++p) {
+#pragma unroll
+                    for (int qq = 0; qq < (D + TC - 1) / TC; ++qq) {
+                        if (TC * qq <= TR * p + TR - 1) {
+                            r0 = (cnt == l) ? TR * p : r0;
+                            c0 = (cnt == l) ? TC * qq : c0;
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+            const bool tile_ok = r0 >= 0;
+            const int tr0 = tile_ok ? r0 : 0;
+            T acc[TR][TC];
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < TC; ++j) acc[i][j] = T(0);
+#ifdef X_UNROLL1
+#pragma unroll 1
+#else
+#pragma unroll 5
+#endif
+            for (int i = 0; i < N; ++i) {
+                T vr[TR], vc[TC];
+#pragma unroll
+                for (int k = 0; k < TR; ++k) vr[k] = DXT[i * LS + tr0 + k];
+#pragma unroll
+                for (int k = 0; k < TC; ++k) vc[k] = DXT[i * LS + c0 + k];
+#pragma unroll
+                for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = fma(vr[i2], vc[j2], acc[i2][j2]);
+            }
+            wsync();  // table reads done before the staging area (inside the table) is rewritten
+            p_commit = pc;
+            st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
+            st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
+            const T* Rn = a.Rn + fc * a.Rn_stride;
+#pragma unroll
+            for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                for (int j2 = 0; j2 < TC; ++j2) {
+                    const int r = tr0 + i2, c = c0 + j2;
+                    const bool w = p_commit && tile_ok && r < D && c <= r;
+                    const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+#ifdef X_NO_NOISE
+                    const T val = T(0.5) * acc[i2][j2];
+#else
+                    const T val = fma(T(0.5), acc[i2][j2], process_noise_entry16<T, M>(Rn, ROT, a, pin, rc, cc));
+#endif
+                    PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = val;
+                }
+            // a gated / failed predict must leave the ORIGINAL state for the update and the commit:
+            // re-stage it from HBM (rare path, wave-uniform guard)
+            if (__any(fvalid && !p_commit)) {
+#pragma unroll
+                for (int t = 0; t < EPL; ++t) {
+                    const int e = l + G * t;
+                    const T v = a.cov[fc * PK + ((e < PK) ? e : (PK - 1))];
+                    PKS[(!p_commit && e < PK) ? e : (LY::DUM - LY::PKS)] = v;
+                }
+                const T v = a.mu[fc * S + ((l < S) ? l : (S - 1))];
+                MUS[(!p_commit && l < S) ? l : (LY::DUM - LY::MUS)] = v;
+            }
+            wsync();
+        }
+    }
+
+    // =========================================================================== update
+    if constexpr (DO_UPDATE) {
+        if (__any(do_u)) {
+            {
+                const int zi = (l < 3) ? l : 0, qi = (l >= 3 && l < 12) ? (l - 3) : 0;
+                const T zv = a.z[fc * 3 + zi], qv = a.Q[fc * 9 + qi];
+                ZQ[(l < 12) ? l : (LY::DUM - LY::ZQ)] = (l < 3) ? zv : qv;
+            }
+            wsync();
+            T zin[3], Qm[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) zin[k] = ZQ[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Qm[k] = ZQ[3 + k];
+            if (M::CHECK_MEAS_FINITE) {
+                bool fin = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fin = fin && m_finite(zin[k]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) fin = fin && m_finite(Qm[k]);
+                st |= (do_u && !fin) ? ST_ERR_NONFINITE_MEAS : 0u;
+                do_u = do_u && fin;
+            }
+            const int midc = M::meas_valid(mid) ? mid : (M::MODEL == 0 ? 0 : 9);
+            const int m = M::meas_dim(midc);
+            const bool so3 = M::meas_is_so3(midc);
+            const bool need_q = so3 || (M::MODEL == 1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const T pad = (r == c) ? T(1) : T(0);
+                    Qm[r * 3 + c] = (r >= m || c >= m) ? pad : Qm[r * 3 + c];
+                }
+            T zval[4];
+            {
+                T qe[4];
+                so3_exp_fast(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
+#pragma unroll
+                for (int k = 0; k < 3; ++k) zval[k] = so3 ? qe[k] : ((k < m) ? zin[k] : T(0));
+                zval[3] = so3 ? qe[3] : T(0);
+            }
+            bool ok1;
+            T rs;
+            T zp[4], zm[4], z0[4];
+            {
+                T mu_r[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
+                {
+                    T arow[D];
+                    load_row<T, D>(PKS, l, arow);
+                    rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, ok1);
+                    wsync();
+                }
+                T col[D];
+                load_column<T, D, LS>(Lc, l, rs, col);
+                T xp[S], xm[S];
+                sigma_pair<T, M>(mu_r, col, __any(need_q), xp, xm);
+                M::measure(xp, midc, zp);
+                M::measure(xm, midc, zm);
+                M::measure(mu_r, midc, z0);
+            }
+            sfence();
+            // ---- mean of Z.  Euclidean: one pass is exact.  SO(3): iterate on the manifold.
+            T zref[4] = {z0[0], z0[1], z0[2], z0[3]};
+            bool zconv = true;
+            if (__any(so3 && do_u)) {
+                bool active = so3;
+                int it = 0;
+                while (__any(active)) {
+                    T rp[3], rm[3], r0v[3], mr[3];
+                    rot_minus(zp, zref, rp);
+                    rot_minus(zm, zref, rm);
+                    rot_minus(z0, zref, r0v);
+                    T m2 = T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T loc = has_pair ? (rp[k] + rm[k]) : T(0);
+                        mr[k] = (row_allreduce(loc) + r0v[k]) * (T(1) / T(N));
+                        m2 += mr[k] * mr[k];
+                    }
+                    T e[4], nq[4];
+                    so3_exp_fast(mr, T(1), e);
+                    quat_mul(zref, e, nq);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) zref[k] = active ? nq[k] : zref[k];
+                    const bool more = m2 > a.mean_tol * a.mean_tol;
+                    const bool capped = more && (it + 1 >= a.mean_max_it);
+                    it += (active && more) ? 1 : 0;
+                    zconv = zconv && !(active && capped);
+                    active = active && more && !capped;
+                }
+            }
+            {
+                T zr[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T loc = has_pair ? ((zp[k] - z0[k]) + (zm[k] - z0[k])) : T(0);
+                    zr[k] = z0[k] + row_allreduce(loc) * (T(1) / T(N));
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) zref[k] = so3 ? zref[k] : zr[k];
+            }
+            sfence();
+            // ---- deltas to the measurement mean, S, innovation
+            T dzp[3], dzm[3], dz0[3], innov[3];
+            {
+                T a3[3] = {T(0), T(0), T(0)}, b3[3] = {T(0), T(0), T(0)}, c3[3] = {T(0), T(0), T(0)},
+                  d3[3] = {T(0), T(0), T(0)};
+                if (__any(so3)) {
+                    rot_minus(zp, zref, a3);
+                    rot_minus(zm, zref, b3);
+                    rot_minus(z0, zref, c3);
+                    rot_minus(zval, zref, d3);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dzp[k] = so3 ? a3[k] : (zp[k] - zref[k]);
+                    dzm[k] = so3 ? b3[k] : (zm[k] - zref[k]);
+                    dz0[k] = so3 ? c3[k] : (z0[k] - zref[k]);
+                    innov[k] = so3 ? d3[k] : (zval[k] - zref[k]);
+                }
+            }
+            T Sm[9];
+            {
+                T u6[6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) {
+                        const T loc = has_pair ? fma(dzp[r], dzp[c], dzm[r] * dzm[c]) : T(0);
+                        u6[r * (r + 1) / 2 + c] = T(0.5) * (row_allreduce(loc) + dz0[r] * dz0[c]);
+                    }
+                Sm[0] = u6[0] + Qm[0];
+                Sm[3] = u6[1] + Qm[3]; Sm[1] = u6[1] + Qm[1];
+                Sm[4] = u6[2] + Qm[4];
+                Sm[6] = u6[3] + Qm[6]; Sm[2] = u6[3] + Qm[2];
+                Sm[7] = u6[4] + Qm[7]; Sm[5] = u6[4] + Qm[5];
+                Sm[8] = u6[5] + Qm[8];
+            }
+            sfence();
+            // ---- cross covariance: Cxz[a][c] = sum_l L[a][l] * 0.5 (dz+_l - dz-_l)[c]
+            T* wrow = has_pair ? (WK + l * 4) : DUMP;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wrow[k] = T(0.5) * rs * (dzp[k] - dzm[k]);
+            wsync();
+            const int la = has_pair ? l : (D - 1);
+            T cx[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const T lv = Lc[j * LS + la];
+                const T v = (j <= la) ? lv : T(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cx[k] = fma(v, WK[j * 4 + k], cx[k]);
+                if ((j & 3) == 3) sfence();
+            }
+            T Kr[3], KSr[3];
+            bool accept;
+            {
+                T Si[9];
+                inverse3(Sm, Si);
+                T maha = T(0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) maha += innov[r] * Si[r * 3 + c] * innov[c];
+                accept = (a.gate_chi2 < T(0)) || (maha <= a.gate_chi2);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Kr[c] = cx[0] * Si[c] + cx[1] * Si[3 + c] + cx[2] * Si[6 + c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) KSr[c] = Kr[0] * Sm[c] + Kr[1] * Sm[3 + c] + Kr[2] * Sm[6 + c];
+            }
+            const T del = Kr[0] * innov[0] + Kr[1] * innov[1] + Kr[2] * innov[2];
+            wsync();  // W rows consumed by every lane before they become K rows
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wrow[k] = Kr[k];
+            wrow[3] = del;
+            wsync();
+            sfence();
+            // ---- Sigma' = Sigma - (K S) K^T, row l on lane l; delta on every lane
+            T srow2[D], d0[D];
+            bool ok2;
+            T rs2;
+            {
+                T arow2[D];
+                load_row<T, D>(PKS, l, arow2);
+#pragma unroll
+                for (int b = 0; b < D; ++b) {
+                    const T kb0 = WK[b * 4], kb1 = WK[b * 4 + 1], kb2 = WK[b * 4 + 2];
+                    arow2[b] -= (KSr[0] * kb0 + KSr[1] * kb1 + KSr[2] * kb2);
+                    srow2[b] = arow2[b];
+                    d0[b] = WK[b * 4 + 3];
+                    if ((b & 3) == 3) sfence();
+                }
+                rs2 = chol16<T, D, LS>(arow2, Lc, l, LY::DUM - LY::LC, ok2);
+                wsync();
+            }
+            sfence();
+            // ---- applyDelta: mu' = mu [+] delta; only the SO(3) rows/columns are re-sampled
+            T e0[4], rp[3], rm[3];
+            {
+                const int lc = has_pair ? l : (D - 1);
+                T c3[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T v = Lc[lc * LS + RT + k] * rs2;
+                    c3[k] = (RT + k >= l) ? v : T(0);
+                }
+                const T v0[3] = {d0[RT], d0[RT + 1], d0[RT + 2]};
+                const T vp[3] = {v0[0] + c3[0], v0[1] + c3[1], v0[2] + c3[2]};
+                const T vm[3] = {v0[0] - c3[0], v0[1] - c3[1], v0[2] - c3[2]};
+                T ep[4], em[4];
+                so3_exp_fast(v0, T(1), e0);
+                so3_exp_fast(vp, T(1), ep);
+                so3_exp_fast(vm, T(1), em);
+                rot_minus(ep, e0, rp);   // log(conj(q e0) (q e+)) = log(conj(e0) e+)
+                rot_minus(em, e0, rm);
+            }
+            sfence();
+            // rotation-rotation block: 0.5 sum (r+ r+^T + r- r-^T)
+            T rr[6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    const T loc = has_pair ? fma(rp[r], rp[c], rm[r] * rm[c]) : T(0);
+                    rr[r * (r + 1) / 2 + c] = T(0.5) * row_allreduce(loc);
+                }
+            wsync();  // K rows consumed
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wrow[k] = T(0.5) * rs2 * (rp[k] - rm[k]);
+            wsync();
+            // cross terms of row l with the three rotation columns
+            T cr[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const T lv = Lc[j * LS + la];
+                const T v = (j <= la) ? lv : T(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cr[k] = fma(v, WK[j * 4 + k], cr[k]);
+                if ((j & 3) == 3) sfence();
+            }
+            wsync();  // W rows consumed
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wrow[k] = cr[k];
+            wsync();
+
+            st |= (do_u && (!ok1 || (accept && !ok2))) ? ST_ERR_CHOLESKY : 0u;
+            st |= (do_u && ok1 && !accept) ? ST_REJECTED_GATE : 0u;
+            st |= (do_u && ok1 && !zconv) ? ST_WARN_MEAN_NOCONV : 0u;
+            u_commit = do_u && ok1 && ok2 && accept;
+
+            sfence();
+            // ---- assemble row l of the resampled covariance
+            {
+                const bool lrot = (l >= RT) && (l < RT + 3);
+                const int li = (l - RT) < 0 ? 0 : ((l - RT) > 2 ? 2 : (l - RT));
+#pragma unroll
+                for (int b = 0; b < D; ++b) {
+                    const bool brot = (b >= RT) && (b < RT + 3);
+                    T v;
+                    if (brot) {   // compile-time per b
+                        const int bi = b - RT;
+                        const int hi = li > bi ? li : bi, lo = li > bi ? bi : li;
+                        T rrv = T(0);
+#pragma unroll
+                        for (int s6 = 0; s6 < 6; ++s6) rrv = (hi * (hi + 1) / 2 + lo == s6) ? rr[s6] : rrv;
+                        v = lrot ? rrv : cr[bi];
+                    } else {
+                        const T other = WK[b * 4 + li];   // cross term computed by lane b for rotation column li
+                        v = lrot ? other : srow2[b];
+                    }
+                    const bool w = u_commit && has_pair && b <= l;
+                    PKS[w ? (l * (l + 1) / 2 + b) : (LY::DUM - LY::PKS)] = v;
+                }
+            }
+            sfence();
+            // ---- new mean mu [+] delta (lane 0 writes the staging copy)
+            {
+                T mu_r[S], nm[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
+                const T q[4] = {mu_r[Q], mu_r[Q + 1], mu_r[Q + 2], mu_r[Q + 3]};
+                T nq[4];
+                quat_mul(q, e0, nq);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s < Q) nm[s] = mu_r[s] + d0[s];
+                    else if (s >= Q + 4) nm[s] = mu_r[s] + d0[s - 1];
+                    else nm[s] = nq[s - Q];
+                }
+                wsync();  // all lanes have read the old mean
+                T* dst = (u_commit && l == 0) ? MUS : DUMP;
+#pragma unroll
+                for (int s = 0; s < S; ++s) dst[s] = nm[s];
+            }
+            wsync();
+        }
+    }
+
+    // =========================================================================== commit
+    const bool changed = p_commit || u_commit;
+    if (changed && fvalid) {
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int e = l + G * t;
+            if (e < PK) a.cov[f * PK + e] = PKS[e];
+        }
+        if (l < S) a.mu[f * S + l] = MUS[l];
+    }
+    if (fvalid && l == 0) a.status[f] = st;
+}
+
+}  // namespace ukfb

@@ -4,6 +4,7 @@
 
 #include "ukf_engine.hpp"
 #include "ukf_kernel.hpp"
+#include "ukf_kernel16.hpp"
 
 namespace ukfb {
 
@@ -25,6 +26,33 @@ template <class T, class M, int G> static int launch_g(ukfb_engine* e, const Lau
         hipLaunchKernelGGL((ukf_kernel<T, M, G, true, false>), gd, bd, lds, e->stream, args);
     else
         hipLaunchKernelGGL((ukf_kernel<T, M, G, false, true>), gd, bd, lds, e->stream, args);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        set_error("kernel launch", err);
+        return UKFB_ERR_HIP;
+    }
+    return UKFB_OK;
+}
+
+// tuned kernel: one DPP row per filter (ukf_kernel16.hpp)
+template <class T, class M> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
+    constexpr int FPW = 4;
+    const int64_t grid = (e->cap + FPW - 1) / FPW;
+    const int lds = FPW * lds_bytes_per_filter16<T, M>();
+    const char* mode = r.do_predict ? (r.do_update ? "cycle" : "predict") : "update";
+    e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
+                     (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
+    e->last_lds = lds;
+    e->last_fpw = FPW;
+    e->last_grid = grid;
+    if (grid == 0) return UKFB_OK;
+    const dim3 gd((unsigned)grid), bd(64);
+    if (r.do_predict && r.do_update)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
+    else if (r.do_predict)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, e->stream, args);
+    else
+        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, e->stream, args);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("kernel launch", err);
@@ -65,7 +93,7 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
     switch (e->cfg.lanes_per_filter) {
         case 64: return launch_g<T, M, 64>(e, r, a);
         case 32: return launch_g<T, M, 32>(e, r, a);
-        default: return launch_g<T, M, 16>(e, r, a);
+        default: return launch_row16<T, M>(e, r, a);
     }
 }
 

@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libukf_batch.so")
+LIB_PATH = os.environ.get("UKFB_LIB", os.path.join(_HERE, "lib", "libukf_batch.so"))  # UKFB_LIB: debug builds only
 
 MODEL_POSE, MODEL_ORIENT = 0, 1
 F64, F32 = 0, 1

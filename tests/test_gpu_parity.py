@@ -127,7 +127,8 @@ def test_orient_predict_update(spe, oracle, prec, G):
     assert (eng.status() == 0).all() and (st2 == 0).all()
     assert max_abs(m_g2, m_o2) <= TOL[prec] and max_abs(c_g2, c_o2) <= TOL[prec]
     rr = eng.rotation_rate()
-    assert max_abs(rr, oracle.orient_rotation_rate(m_g2, gyro, eng.earth_rotation)) <= 1e-12
+    # read-out of latched input and mean (the fp32 engine stores the gyro sample in float)
+    assert max_abs(rr, oracle.orient_rotation_rate(m_g2, gyro, eng.earth_rotation)) <= (1e-12 if prec == 0 else 1e-6)
 
 
 def test_pose_trajectory_100_cycles_fp64(spe, oracle):

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Build gate for the tuned kernels (ukf_kernel16): no scratch, no AGPR.
+
+ROCm 7.2's hipcc places VGPR spill / live-range-split copies at the join label of a divergent `if`
+in front of the EXEC restore; reached through s_cbranch_execz they save nothing (see the note in
+slam-pose_estimation_amd/csrc/ukf_kernel16.hpp).  A tuned kernel that needs spills is therefore
+rejected at build time instead of being trusted.  Usage: check_resources.py <hipcc remark log>..."""
+import re
+import sys
+
+
+def parse(text):
+    out, cur = [], None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            out.append(cur)
+            continue
+        for key, pat in (("vgpr", r"remark:\s+VGPRs: (\d+)"), ("agpr", r"remark:\s+AGPRs: (\d+)"),
+                         ("scratch", r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"remark:\s+Occupancy \[waves/SIMD\]: (\d+)"),
+                         ("lds", r"remark:\s+LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def main(paths):
+    bad, rows = [], []
+    for p in paths:
+        for k in parse(open(p).read()):
+            if "ukf_kernel" not in k["name"]:
+                continue
+            rows.append(k)
+            if "ukf_kernel16" in k["name"] and (k.get("scratch", 0) or k.get("agpr", 0)):
+                bad.append(k)
+    for k in rows:
+        print(f"{k['name'][:70]:70s} vgpr={k.get('vgpr')} agpr={k.get('agpr')} scratch={k.get('scratch')} "
+              f"occ={k.get('occupancy')}")
+    if bad:
+        print("ERROR: tuned kernels with spills (unsafe with this toolchain):", [b["name"] for b in bad])
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -277,7 +277,7 @@ template <class T> UKFB_DEV void so3_log(const T (&q)[4], T (&r)[3]) {
 // q <- q * exp(v, scale)
 template <class T> UKFB_DEV void so3_boxplus(T (&q)[4], const T (&v)[3], T scale) {
     T d[4], r[4];
-    so3_exp(v, scale, d);
+    so3_exp_fast(v, scale, d);
     quat_mul(q, d, r);
     q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = r[3];
 }
@@ -287,7 +287,7 @@ template <class T> UKFB_DEV void so3_boxminus(const T (&q)[4], const T (&other)[
     const T oc[4] = {-other[QX], -other[QY], -other[QZ], other[QW]};
     T d[4];
     quat_mul(oc, q, d);
-    so3_log(d, r);
+    so3_log_fast(d, r);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -77,7 +77,11 @@ template <class T, class M> struct Layout {
     static constexpr int LC_OFF = 0;                      // D*LS : packed Sigma staging / L columns / small matrices
     static constexpr int DX_OFF = D * LS;                 // N*DS : [dx(0..D-1) | dz(0..2)] per sigma point
     static constexpr int MISC_OFF = DX_OFF + N * DS;      // 72   : MU MD ROT ZQ DEL
-    static constexpr int PF = MISC_OFF + 72;
+    static constexpr int PK = D * (D + 1) / 2;
+    static constexpr int PKP = (PK + VEC - 1) / VEC * VEC;
+    static constexpr int PKS_OFF = MISC_OFF + 72;         // PKP  : packed covariance of the current state
+    static constexpr int DUM_OFF = PKS_OFF + PKP;         // 16   : sink for lane-predicated stores
+    static constexpr int PF = DUM_OFF + 16;
     // small matrices that reuse the (dead) factor region between two Choleskys
     static constexpr int SMAT = 0, CXZ = 12, KMAT = 52, KEND = 92;
     static_assert(D + 3 <= DS, "delta row too small");
@@ -100,16 +104,16 @@ template <int G> UKFB_DEV float gshfl(float v, int src) { return __shfl(v, src, 
 // the factor is published to Lc (column-major, stride LS, zeros above the diagonal) as soon as it
 // is final and read back (LDS broadcast) for the trailing update.  false: a pivot was <= 0
 // (Eigen LLT: NumericalIssue).
-template <class T, int D, int LS, int G> UKFB_DEV bool chol_rows_to_lds(T (&a)[D], T* Lc, int l) {
+template <class T, int D, int LS, int G> UKFB_DEV bool chol_rows_to_lds(T (&a)[D], T* Lc, int l, int dum) {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const T akk = gshfl<G>(a[k], k);
         ok = ok && (akk > T(0));
-        const T d = m_sqrt(akk);
-        const T inv = T(1) / d;
+        const T inv = fast_rsqrt(akk);
+        const T d = akk * inv;
         const T lk = (l > k) ? a[k] * inv : ((l == k) ? d : T(0));
-        if (l < D) Lc[k * LS + l] = lk;
+        Lc[(l < D) ? (k * LS + l) : dum] = lk;
         wsync();
 #pragma unroll
         for (int c = k + 1; c < D; ++c) a[c] -= lk * Lc[k * LS + c];
@@ -137,27 +141,27 @@ UKFB_DEV void sigma_point(const T (&mu)[M::S], const T* Lc, const T (&d0)[M::D],
 // ukfom meanSigmaPoints on the state manifold: lanes hold the sigma points, deltas go through the
 // group's LDS table, lanes 0..D-1 each sum one tangent component in sigma-point order.
 template <class T, class M, int G, int RND, int DS>
-UKFB_DEV bool mean_loop_state(const T (&X)[RND][M::S], T (&ref)[M::S], T* DX, T* MD, int l, T tol, int max_it) {
+UKFB_DEV bool mean_loop_state(const T (&X)[RND][M::S], T (&ref)[M::S], T* DX, T* MD, T* DUMP, int l, T tol, int max_it) {
     constexpr int D = M::D, S = M::S, N = 2 * D + 1;
     bool active = true, conv = true;
     int it = 0;
+    const int lc = (l < D) ? l : (D - 1);
     for (;;) {
 #pragma unroll
         for (int r = 0; r < RND; ++r) {
             const int i = l + G * r;
-            if (i < N) {
-                T d[D];
-                M::boxminus(X[r], ref, d);
+            T d[D];
+            M::boxminus(X[r], ref, d);
+            T* row = (i < N) ? (DX + i * DS) : DUMP;
 #pragma unroll
-                for (int c = 0; c < D; ++c) DX[i * DS + c] = d[c];
-            }
+            for (int c = 0; c < D; ++c) row[c] = d[c];
         }
         wsync();
-        if (l < D) {
+        {
             T md = T(0);
 #pragma unroll 5
-            for (int i = 0; i < N; ++i) md += DX[i * DS + l];
-            MD[l] = md / T(N);
+            for (int i = 0; i < N; ++i) md += DX[i * DS + lc];
+            MD[(l < D) ? l : 15] = md * (T(1) / T(N));   // MD has 16 slots; D <= 13
         }
         wsync();
         T mdv[D];
@@ -173,17 +177,11 @@ UKFB_DEV bool mean_loop_state(const T (&X)[RND][M::S], T (&ref)[M::S], T* DX, T*
         M::boxplus(nref, mdv);
 #pragma unroll
         for (int s = 0; s < S; ++s) ref[s] = active ? nref[s] : ref[s];
-        const T norm = m_sqrt(n2);
-        if (active) {
-            if (norm > tol) {
-                if (++it >= max_it) {
-                    active = false;
-                    conv = false;
-                }
-            } else {
-                active = false;
-            }
-        }
+        const bool more = n2 > tol * tol;
+        const bool capped = more && (it + 1 >= max_it);
+        it += (active && more) ? 1 : 0;
+        conv = conv && !(active && capped);
+        active = active && more && !capped;
         if (!__any(active)) break;
     }
     return conv;
@@ -218,7 +216,7 @@ template <class T> UKFB_DEV void inverse3(const T (&m)[9], T (&r)[9]) {
     const T c10 = m[7] * m[2] - m[8] * m[1];
     const T c20 = m[1] * m[5] - m[2] * m[4];
     const T det = c00 * m[0] + c10 * m[3] + c20 * m[6];
-    const T invdet = T(1) / det;
+    const T invdet = fast_rcp(det);
     r[0] = c00 * invdet;
     r[1] = c10 * invdet;
     r[2] = c20 * invdet;
@@ -264,7 +262,7 @@ UKFB_DEV T process_noise_entry(const T* Rn, const T* ROT, const KArgs<T>& a, con
 }
 
 // minimum waves per SIMD the register allocator must leave room for (LDS admits about this many)
-template <class T> constexpr int min_waves_per_simd() { return sizeof(T) == 8 ? 2 : 4; }
+template <class T> constexpr int min_waves_per_simd() { return 2; }
 
 template <class T, class M, int G, bool DO_PREDICT, bool DO_UPDATE>
 __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const KArgs<T> a) {
@@ -285,6 +283,8 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
     T* DX = base + LY::DX_OFF;
     T* MS = base + LY::MISC_OFF;
     T* MU = MS; T* MD = MS + 16; T* ROT = MS + 32; T* ZQ = MS + 44; T* DEL = MS + 56;
+    T* PKS = base + LY::PKS_OFF;
+    T* DUMP = base + LY::DUM_OFF;
 
     // this lane's packed covariance entries
     int er[EPL], ec[EPL];
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 
     uint32_t st = ST_OK;
     const bool live = fvalid && (a.initialised[fc] != 0);
-    if (fvalid && !live) st |= ST_UNINITIALISED;
+    st |= (fvalid && !live) ? ST_UNINITIALISED : 0u;
 
     // ---- time gate (UnscentedKalmanFilter.hpp:83-125)
     bool do_p = false, p_error = false;
@@ -314,13 +314,12 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
         } else {
             dt = a.dt ? a.dt[fc] : a.dt_uniform;
         }
-        if (live) {
-            if (first) st |= ST_SKIPPED_FIRST_TS;
-            else if (dt < 0.0) { st |= ST_ERR_NEG_DT; p_error = true; }
-            else if (dt <= a.min_dt) st |= ST_SKIPPED_SMALL_DT;
-            else if (dt > a.max_dt) { st |= ST_ERR_DT_TOO_LARGE; p_error = true; }
-            else do_p = true;
-        }
+        const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
+        const uint32_t code = first ? ST_SKIPPED_FIRST_TS
+                                    : (neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u)));
+        st |= live ? code : 0u;
+        p_error = live && !first && (neg || (!small && large));
+        do_p = live && code == 0u;
         dtT = T(dt);
     }
 
@@ -331,21 +330,25 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
         mid = a.meas ? a.meas[fc] : a.meas_uniform;
         const bool act = M::meas_valid(mid) && (a.active ? a.active[fc] != 0 : true);
         do_u = live && act && !p_error;
-        if (live && !do_u) st |= ST_INACTIVE;
+        st |= (live && !do_u) ? ST_INACTIVE : 0u;
     }
 
     // ---- load: packed covariance + mean -> LDS -> registers (mean replicated, row l on lane l)
 #pragma unroll
-    for (int t = 0; t < EPL; ++t)
-        if (ev[t]) Lc[l + G * t] = a.cov[fc * PK + l + G * t];
-    if (l < S) MU[l] = a.mu[fc * S + l];
+    for (int t = 0; t < EPL; ++t) {
+        const int e = l + G * t;
+        const T v = a.cov[fc * PK + (ev[t] ? e : (PK - 1))];
+        PKS[ev[t] ? e : (LY::DUM_OFF - LY::PKS_OFF)] = v;
+    }
+    {
+        const T v = a.mu[fc * S + ((l < S) ? l : (S - 1))];
+        MU[(l < S) ? l : (LY::DUM_OFF - LY::MISC_OFF)] = v;
+    }
     wsync();
-    T mu_r[S], rowv[D];
+    T mu_r[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) mu_r[s] = MU[s];
-#pragma unroll
-    for (int j = 0; j < D; ++j) rowv[j] = (l < D && j <= l) ? Lc[l * (l + 1) / 2 + j] : T(0);
-    wsync();
+    const int lrow = (l < D) ? l : (D - 1);   // row of the packed covariance this lane reads
 
     T zero_d[D];
 #pragma unroll
@@ -375,16 +378,15 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                 T q[4], rot[9];
                 M::orientation(mu_r, q);
                 quat_to_matrix(q, rot);
-                if (l == 0) {
+                T* dst = (l == 0) ? ROT : DUMP;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) ROT[k] = rot[k];
-                }
+                for (int k = 0; k < 9; ++k) dst[k] = rot[k];
             }
 
             T arow[D];
 #pragma unroll
-            for (int j = 0; j < D; ++j) arow[j] = rowv[j];
-            const bool ok = chol_rows_to_lds<T, D, LS, G>(arow, Lc, l);
+            for (int j = 0; j < D; ++j) arow[j] = (j <= lrow) ? PKS[lrow * (lrow + 1) / 2 + j] : T(0);
+            const bool ok = chol_rows_to_lds<T, D, LS, G>(arow, Lc, l, LY::DUM_OFF - LY::LC_OFF);
 
             T X[RND][S];
 #pragma unroll
@@ -397,17 +399,16 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
             for (int s = 0; s < S; ++s) ref[s] = gshfl<G>(X[0][s], 0);
 
-            const bool conv = mean_loop_state<T, M, G, RND, DS>(X, ref, DX, MD, l, a.mean_tol, a.mean_max_it);
+            const bool conv = mean_loop_state<T, M, G, RND, DS>(X, ref, DX, MD, DUMP, l, a.mean_tol, a.mean_max_it);
 
 #pragma unroll
             for (int r = 0; r < RND; ++r) {
                 const int i = l + G * r;
-                if (i < N) {
-                    T d[D];
-                    M::boxminus(X[r], ref, d);
+                T d[D];
+                M::boxminus(X[r], ref, d);
+                T* row = (i < N) ? (DX + i * DS) : DUMP;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) DX[i * DS + c] = d[c];
-                }
+                for (int c = 0; c < D; ++c) row[c] = d[c];
             }
             wsync();
             cov_entries<T, N, DS, EPL>(DX, er, ec, Pn);
@@ -417,22 +418,13 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
             wsync();
 
             p_commit = do_p && ok;
-            if (do_p && !ok) st |= ST_ERR_CHOLESKY;
-            if (p_commit && !conv) st |= ST_WARN_MEAN_NOCONV;
+            st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
+            st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
 #pragma unroll
-            for (int t = 0; t < EPL; ++t)
-                if (ev[t]) Lc[l + G * t] = Pn[t];
+            for (int t = 0; t < EPL; ++t) PKS[(ev[t] && p_commit) ? (l + G * t) : (LY::DUM_OFF - LY::PKS_OFF)] = Pn[t];
 #pragma unroll
             for (int s = 0; s < S; ++s) mu_r[s] = p_commit ? ref[s] : mu_r[s];
             wsync();
-            if constexpr (DO_UPDATE) {
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    const T v = (l < D && j <= l) ? Lc[l * (l + 1) / 2 + j] : T(0);
-                    rowv[j] = p_commit ? v : rowv[j];
-                }
-                wsync();
-            }
         }
     }
 
@@ -446,7 +438,11 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 
     if constexpr (DO_UPDATE) {
         if (__any(do_u)) {
-            if (l < 12) ZQ[l] = (l < 3) ? a.z[fc * 3 + l] : a.Q[fc * 9 + (l - 3)];
+            {
+                const int zi = (l < 3) ? l : 0, qi = (l >= 3 && l < 12) ? (l - 3) : 0;
+                const T zv = a.z[fc * 3 + zi], qv = a.Q[fc * 9 + qi];
+                ZQ[(l < 12) ? l : (LY::DUM_OFF - LY::MISC_OFF - 44)] = (l < 3) ? zv : qv;
+            }
             wsync();
             T zin[3], Qm[9];
 #pragma unroll
@@ -459,10 +455,8 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                 for (int k = 0; k < 3; ++k) fin = fin && m_finite(zin[k]);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) fin = fin && m_finite(Qm[k]);
-                if (do_u && !fin) {
-                    st |= ST_ERR_NONFINITE_MEAS;
-                    do_u = false;
-                }
+                st |= (do_u && !fin) ? ST_ERR_NONFINITE_MEAS : 0u;
+                do_u = do_u && fin;
             }
             const int midc = M::meas_valid(mid) ? mid : (M::MODEL == 0 ? 0 : 9);
             const int m = M::meas_dim(midc);
@@ -471,12 +465,14 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (r >= m || c >= m) Qm[r * 3 + c] = (r == c) ? T(1) : T(0);
+                for (int c = 0; c < 3; ++c) {
+                    const T pad = (r == c) ? T(1) : T(0);
+                    Qm[r * 3 + c] = (r >= m || c >= m) ? pad : Qm[r * 3 + c];
+                }
             T zval[4];
             {
                 T qe[4];
-                so3_exp(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
+                so3_exp_fast(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
 #pragma unroll
                 for (int k = 0; k < 3; ++k) zval[k] = so3 ? qe[k] : ((k < m) ? zin[k] : T(0));
                 zval[3] = so3 ? qe[3] : T(0);
@@ -484,8 +480,8 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 
             T arow[D];
 #pragma unroll
-            for (int j = 0; j < D; ++j) arow[j] = rowv[j];
-            const bool ok1 = chol_rows_to_lds<T, D, LS, G>(arow, Lc, l);
+            for (int j = 0; j < D; ++j) arow[j] = (j <= lrow) ? PKS[lrow * (lrow + 1) / 2 + j] : T(0);
+            const bool ok1 = chol_rows_to_lds<T, D, LS, G>(arow, Lc, l, LY::DUM_OFF - LY::LC_OFF);
 
             T X[RND][S], Z[RND][4];
 #pragma unroll
@@ -499,6 +495,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
             for (int k = 0; k < 4; ++k) zref[k] = gshfl<G>(Z[0][k], 0);
             bool zconv = true;
+            const bool any_so3 = __any(so3);
             {
                 bool active = true;
                 int it = 0;
@@ -506,23 +503,21 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
                     for (int r = 0; r < RND; ++r) {
                         const int i = l + G * r;
-                        if (i < N) {
-                            T dz[3];
-                            if (so3) so3_boxminus(Z[r], zref, dz);
-                            else {
+                        T dz[3], dq[3] = {T(0), T(0), T(0)};
+                        if (any_so3) so3_boxminus(Z[r], zref, dq);   // wave-uniform
 #pragma unroll
-                                for (int k = 0; k < 3; ++k) dz[k] = Z[r][k] - zref[k];
-                            }
+                        for (int k = 0; k < 3; ++k) dz[k] = so3 ? dq[k] : (Z[r][k] - zref[k]);
+                        T* row = (i < N) ? (DX + i * DS + ZO) : DUMP;
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) DX[i * DS + ZO + k] = dz[k];
-                        }
+                        for (int k = 0; k < 3; ++k) row[k] = dz[k];
                     }
                     wsync();
-                    if (l < 3) {
+                    {
+                        const int lz = (l < 3) ? l : 2;
                         T md = T(0);
 #pragma unroll 5
-                        for (int i = 0; i < N; ++i) md += DX[i * DS + ZO + l];
-                        MD[l] = md / T(N);
+                        for (int i = 0; i < N; ++i) md += DX[i * DS + ZO + lz];
+                        MD[(l < 3) ? l : 15] = md * (T(1) / T(N));
                     }
                     wsync();
                     T mdv[3];
@@ -535,24 +530,18 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                     T nz[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) nz[k] = zref[k];
-                    if (so3) so3_boxplus(nz, mdv, T(1));
-                    else {
+                    T nq[4] = {zref[0], zref[1], zref[2], zref[3]};
+                    if (any_so3) so3_boxplus(nq, mdv, T(1));   // wave-uniform
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) nz[k] += mdv[k];
-                    }
+                    for (int k = 0; k < 3; ++k) nz[k] = so3 ? nq[k] : (nz[k] + mdv[k]);
+                    nz[3] = so3 ? nq[3] : nz[3];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) zref[k] = active ? nz[k] : zref[k];
-                    const T norm = m_sqrt(n2);
-                    if (active) {
-                        if (norm > a.mean_tol) {
-                            if (++it >= a.mean_max_it) {
-                                active = false;
-                                zconv = false;
-                            }
-                        } else {
-                            active = false;
-                        }
-                    }
+                    const bool more = n2 > a.mean_tol * a.mean_tol;
+                    const bool capped = more && (it + 1 >= a.mean_max_it);
+                    it += (active && more) ? 1 : 0;
+                    zconv = zconv && !(active && capped);
+                    active = active && more && !capped;
                     if (!__any(active)) break;
                 }
             }
@@ -560,20 +549,19 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
             for (int r = 0; r < RND; ++r) {
                 const int i = l + G * r;
-                if (i < N) {
-                    T dz[3];
-                    if (so3) so3_boxminus(Z[r], zref, dz);
-                    else {
+                const int ic = (i < N) ? i : (N - 1);
+                T dz[3], dq[3] = {T(0), T(0), T(0)};
+                if (any_so3) so3_boxminus(Z[r], zref, dq);
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) dz[k] = Z[r][k] - zref[k];
-                    }
+                for (int k = 0; k < 3; ++k) dz[k] = so3 ? dq[k] : (Z[r][k] - zref[k]);
+                T* row = (i < N) ? (DX + i * DS) : DUMP;   // DUMP has 16 slots = DS
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) DX[i * DS + ZO + k] = dz[k];
-                    T dx[D];
-                    M::boxminus(X[r], mu_r, dx);
+                for (int k = 0; k < 3; ++k) row[ZO + k] = dz[k];
+                // (mu [+] d) [-] mu = d: the state deltas are the signed factor columns themselves
+                const int jj = (ic > 0) ? ((ic - 1) >> 1) : 0;
+                const T sg = (ic == 0) ? T(0) : ((ic & 1) ? T(1) : T(-1));
 #pragma unroll
-                    for (int c = 0; c < D; ++c) DX[i * DS + c] = dx[c];
-                }
+                for (int c = 0; c < D; ++c) row[c] = sg * Lc[jj * LS + c];
             }
             wsync();
             // ---- S = 0.5 sum dz dz^T + Q (9 entries), Cxz = 0.5 sum dx dz^T (3D entries)
@@ -581,8 +569,9 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                 constexpr int NE = 9 + 3 * D, TPL = (NE + G - 1) / G;
 #pragma unroll
                 for (int t = 0; t < TPL; ++t) {
-                    const int qi = l + G * t;
-                    if (qi < NE) {
+                    const int q0 = l + G * t;
+                    const int qi = (q0 < NE) ? q0 : (NE - 1);
+                    {
                         const bool isS = qi < 9;
                         const int ra = isS ? (ZO + qi / 3) : ((qi - 9) / 3);
                         const int cb = ZO + (isS ? (qi % 3) : ((qi - 9) % 3));
@@ -590,14 +579,11 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll 5
                         for (int i = 0; i < N; ++i) acc += DX[i * DS + ra] * DX[i * DS + cb];
                         acc *= T(0.5);
-                        if (isS) {
-                            T qv = T(0);
+                        T qv = T(0);
 #pragma unroll
-                            for (int s = 0; s < 9; ++s) qv = (qi == s) ? Qm[s] : qv;
-                            Lc[LY::SMAT + qi] = acc + qv;
-                        } else {
-                            Lc[LY::CXZ + (qi - 9)] = acc;
-                        }
+                        for (int s = 0; s < 9; ++s) qv = (qi == s) ? Qm[s] : qv;
+                        const int dst = isS ? (LY::SMAT + qi) : (LY::CXZ + (qi - 9));
+                        Lc[(q0 < NE) ? dst : (LY::DUM_OFF - LY::LC_OFF)] = isS ? (acc + qv) : acc;
                     }
                 }
             }
@@ -608,10 +594,11 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
             for (int k = 0; k < 9; ++k) Sm[k] = Lc[LY::SMAT + k];
             inverse3(Sm, Si);
             T innov[3];
-            if (so3) so3_boxminus(zval, zref, innov);
-            else {
+            {
+                T iq[3] = {T(0), T(0), T(0)};
+                if (any_so3) so3_boxminus(zval, zref, iq);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) innov[k] = zval[k] - zref[k];
+                for (int k = 0; k < 3; ++k) innov[k] = so3 ? iq[k] : (zval[k] - zref[k]);
             }
             T maha = T(0);
 #pragma unroll
@@ -643,11 +630,10 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                 T del = T(0);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) del += Kr[k] * innov[k];
-                if (l < D) {
+                T* krow = (l < D) ? (Lc + LY::KMAT + l * 3) : DUMP;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) Lc[LY::KMAT + l * 3 + k] = Kr[k];
-                    DEL[l] = del;
-                }
+                for (int k = 0; k < 3; ++k) krow[k] = Kr[k];
+                DEL[(l < D) ? l : 15] = del;   // DEL has 16 slots
             }
             wsync();
             T arow2[D], dl[D];
@@ -656,11 +642,11 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                 T s = T(0);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) s += KSr[k] * Lc[LY::KMAT + b * 3 + k];
-                arow2[b] = rowv[b] - s;
+                arow2[b] = ((b <= lrow) ? PKS[lrow * (lrow + 1) / 2 + b] : T(0)) - s;
                 dl[b] = DEL[b];
             }
             wsync();
-            const bool ok2 = chol_rows_to_lds<T, D, LS, G>(arow2, Lc, l);
+            const bool ok2 = chol_rows_to_lds<T, D, LS, G>(arow2, Lc, l, LY::DUM_OFF - LY::LC_OFF);
 
             // ---- applyDelta: resample around mu + delta
 #pragma unroll
@@ -673,22 +659,19 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
             for (int r = 0; r < RND; ++r) {
                 const int i = l + G * r;
-                if (i < N) {
-                    T d[D];
-                    M::boxminus(X[r], mu2, d);
+                T d[D];
+                M::boxminus(X[r], mu2, d);
+                T* row = (i < N) ? (DX + i * DS) : DUMP;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) DX[i * DS + c] = d[c];
-                }
+                for (int c = 0; c < D; ++c) row[c] = d[c];
             }
             wsync();
             cov_entries<T, N, DS, EPL>(DX, er, ec, Pu);
             wsync();
 
-            if (do_u) {
-                if (!ok1 || (accept && !ok2)) st |= ST_ERR_CHOLESKY;
-                else if (!accept) st |= ST_REJECTED_GATE;
-                if (ok1 && !zconv) st |= ST_WARN_MEAN_NOCONV;
-            }
+            st |= (do_u && (!ok1 || (accept && !ok2))) ? ST_ERR_CHOLESKY : 0u;
+            st |= (do_u && ok1 && !accept) ? ST_REJECTED_GATE : 0u;
+            st |= (do_u && ok1 && !zconv) ? ST_WARN_MEAN_NOCONV : 0u;
             u_commit = do_u && ok1 && ok2 && accept;
         }
     }
@@ -696,26 +679,18 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
     // =========================================================================== commit
     const bool changed = p_commit || u_commit;
     if (__any(changed)) {
-        if (u_commit) {
 #pragma unroll
-            for (int t = 0; t < EPL; ++t)
-                if (ev[t]) Lc[l + G * t] = Pu[t];
-        } else if (DO_UPDATE && p_commit) {
-            if (l < D) {
+        for (int t = 0; t < EPL; ++t) PKS[(ev[t] && u_commit) ? (l + G * t) : (LY::DUM_OFF - LY::PKS_OFF)] = Pu[t];
+        {
+            T* dst = (l == 0) ? MU : DUMP;
 #pragma unroll
-                for (int j = 0; j < D; ++j)
-                    if (j <= l) Lc[l * (l + 1) / 2 + j] = rowv[j];
-            }
-        }
-        if (l == 0) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) MU[s] = u_commit ? mu2[s] : mu_r[s];
+            for (int s = 0; s < S; ++s) dst[s] = u_commit ? mu2[s] : mu_r[s];
         }
         wsync();
         if (changed && fvalid) {
 #pragma unroll
             for (int t = 0; t < EPL; ++t)
-                if (ev[t]) a.cov[f * PK + l + G * t] = Lc[l + G * t];
+                if (ev[t]) a.cov[f * PK + l + G * t] = PKS[l + G * t];
             if (l < S) a.mu[f * S + l] = MU[l];
         }
     }

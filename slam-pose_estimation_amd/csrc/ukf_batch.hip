@@ -121,6 +121,39 @@ int stage_measurements(ukfb_engine* e, const double* z, const double* Q, const i
     return UKFB_OK;
 }
 
+// Racc = Rn with block(6,6,3,3) = 2 acc.cov for every stored noise matrix (PoseUKF.cpp:190-191)
+template <class T> __global__ void build_racc_kernel(const T* Rn, T* Racc, int64_t nmat, int D, const T* acc_cov9) {
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= nmat * D * D) return;
+    const int rc = int(i % (int64_t(D) * D)), r = rc / D, c = rc % D;
+    const bool vel = r >= 6 && r < 9 && c >= 6 && c < 9;
+    Racc[i] = vel ? T(2) * acc_cov9[(r - 6) * 3 + (c - 6)] : Rn[i];
+}
+
+int rebuild_racc(ukfb_engine* e) {
+    if (e->model != UKFB_MODEL_POSE) return UKFB_OK;
+    const int64_t nmat = e->Rn_per_filter ? e->cap : 1;
+    const size_t dd = size_t(e->D) * e->D;
+    if (e->Racc) HIP_TRY(hipFree(e->Racc));
+    e->Racc = nullptr;
+    HIP_TRY(hipMalloc(&e->Racc, size_t(nmat) * dd * e->tsize));
+    void* ac = nullptr;
+    HIP_TRY(hipMalloc(&ac, 9 * e->tsize));
+    int rc = upload(e, ac, 0, e->acc_cov, 9);
+    if (rc) return rc;
+    const int64_t total = nmat * int64_t(dd);
+    const int blocks = int((total + 255) / 256);
+    if (e->prec == UKFB_F64)
+        hipLaunchKernelGGL(build_racc_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->Rn),
+                           static_cast<double*>(e->Racc), nmat, e->D, static_cast<const double*>(ac));
+    else
+        hipLaunchKernelGGL(build_racc_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const float*>(e->Rn),
+                           static_cast<float*>(e->Racc), nmat, e->D, static_cast<const float*>(ac));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(ac));
+    return UKFB_OK;
+}
+
 __global__ void or_reduce_kernel(const uint32_t* st, int64_t n, uint32_t* out) {
     uint32_t v = 0;
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
@@ -215,6 +248,8 @@ int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, i
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    rc = rebuild_racc(e);
+    if (rc) return rc;
     *out = e;
     return UKFB_OK;
 }
@@ -223,7 +258,7 @@ int ukfb_destroy(ukfb_engine* e) {
     if (!e) return UKFB_OK;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->in_a, e->in_b, e->z_stage, e->Q_stage,
+    void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->in_a, e->in_b, e->z_stage, e->Q_stage,
                     e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -359,9 +394,11 @@ int ukfb_set_process_noise(ukfb_engine* e, const double* R) {
     if (e->Rn_per_filter) {
         std::vector<double> all(size_t(e->cap) * dd);
         for (int64_t i = 0; i < e->cap; ++i) std::memcpy(all.data() + size_t(i) * dd, R, dd * sizeof(double));
-        return upload(e, e->Rn, 0, all.data(), all.size());
+        int rc = upload(e, e->Rn, 0, all.data(), all.size());
+        return rc ? rc : rebuild_racc(e);
     }
-    return upload(e, e->Rn, 0, R, dd);
+    int rc = upload(e, e->Rn, 0, R, dd);
+    return rc ? rc : rebuild_racc(e);
 }
 
 int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t count, const double* R) {
@@ -381,7 +418,8 @@ int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t cou
         int rc = upload(e, e->Rn, 0, all.data(), all.size());
         if (rc) return rc;
     }
-    return upload(e, e->Rn, size_t(first) * dd, R, size_t(count) * dd);
+    int rc = upload(e, e->Rn, size_t(first) * dd, R, size_t(count) * dd);
+    return rc ? rc : rebuild_racc(e);
 }
 
 int ukfb_get_process_noise(ukfb_engine* e, int64_t filter, double* R) {
@@ -397,7 +435,11 @@ int ukfb_pose_set_acceleration(ukfb_engine* e, int64_t first, int64_t count, con
     if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
     HIP_TRY(hipSetDevice(e->device));
-    if (acc_cov) std::memcpy(e->acc_cov, acc_cov, 9 * sizeof(double));
+    if (acc_cov) {
+        std::memcpy(e->acc_cov, acc_cov, 9 * sizeof(double));
+        int rc = rebuild_racc(e);
+        if (rc) return rc;
+    }
     if (acc_mu) return upload(e, e->in_a, size_t(first) * 3, acc_mu, size_t(count) * 3);
     return UKFB_OK;
 }

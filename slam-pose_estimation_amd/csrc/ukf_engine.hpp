@@ -28,6 +28,7 @@ struct ukfb_engine {
 
     // process noise: batch-uniform D*D, or per filter after ukfb_set_process_noise_per_filter
     void* Rn = nullptr;
+    void* Racc = nullptr;  // Pose: acceleration-branch noise (Rn with the velocity block replaced)
     bool Rn_per_filter = false;
     std::vector<double> Rn_host;  // uniform copy
 

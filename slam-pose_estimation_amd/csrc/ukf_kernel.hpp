@@ -45,6 +45,7 @@ template <class T> struct KArgs {
     // ---- predict
     const T* Rn;                 // process_noise_cov, D*D row-major; per filter if Rn_stride != 0
     int64_t Rn_stride;
+    const T* Racc;               // Pose: Rn with block(6,6,3,3) = 2 acc.cov (same stride as Rn)
     const T* in_a;               // Pose: acc.mu [n][3] (may be null) ; Orient: acceleration.mu [n][3]
     const T* in_b;               // Orient: rotation_rate.mu [n][3]
     T acc_cov[9];                // Pose: acceleration.cov (batch-uniform)

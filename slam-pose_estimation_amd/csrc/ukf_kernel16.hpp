@@ -58,14 +58,29 @@ template <class T> UKFB_DEV T row_allreduce(T v) {
 // ---------------------------------------------------------------------------------------------
 // manifold traits for the tuned kernel
 // ---------------------------------------------------------------------------------------------
+constexpr unsigned long long nib(int i, int v) { return (unsigned long long)(v & 15) << (4 * i); }
+
 template <class M> struct MT;
 template <class T> struct MT<PoseM<T>> {
     static constexpr int Q = 3;    // stored offset of the quaternion
     static constexpr int RT = 3;   // tangent offset of the rotation
     static constexpr int TR = 2, TC = 3;  // covariance tile
+    // stored index of measurement component k for model id 0..8 (PoseUKF.cpp:7-69), 15 = unused
+    static constexpr unsigned long long SEL0 = nib(0, 0) | nib(1, 0) | nib(2, 2) | nib(3, 15) | nib(4, 7) | nib(5, 7) |
+                                               nib(6, 9) | nib(7, 7) | nib(8, 10);
+    static constexpr unsigned long long SEL1 = nib(0, 1) | nib(1, 1) | nib(2, 15) | nib(3, 15) | nib(4, 8) | nib(5, 8) |
+                                               nib(6, 15) | nib(7, 12) | nib(8, 11);
+    static constexpr unsigned long long SEL2 = nib(0, 2) | nib(1, 15) | nib(2, 15) | nib(3, 15) | nib(4, 9) | nib(5, 15) |
+                                               nib(6, 15) | nib(7, 15) | nib(8, 12);
+    static constexpr bool HAS_EUCLID_MEAS = true;
+    // orientation-dependent measurement (model id 3): the quaternion itself
+    UKFB_DEV static void gen_measure(const T (&x)[13], T (&z)[4]) { z[0] = x[3]; z[1] = x[4]; z[2] = x[5]; z[3] = x[6]; }
 };
 template <class T> struct MT<OrientM<T>> {
     static constexpr int Q = 0, RT = 0, TR = 3, TC = 3;
+    static constexpr unsigned long long SEL0 = 0, SEL1 = 0, SEL2 = 0;
+    static constexpr bool HAS_EUCLID_MEAS = false;
+    UKFB_DEV static void gen_measure(const T (&x)[14], T (&z)[4]) { OrientM<T>::measure(x, 9, z); }
 };
 
 template <class T, class M> struct Layout16 {
@@ -101,43 +116,40 @@ template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layo
 UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
 
 template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
-    T my_rs = T(0);
     bool good = true;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        Lc[(l < D) ? (k * LS + l) : dum] = a[k];
+        // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
+        Lc[(l < D) ? (k * LS + l) : dum] = (l >= k) ? a[k] : T(0);
         wsync();
         const T akk = Lc[k * LS + k];
         good = good && (akk > T(0));
         const T rs = fast_rsqrt(akk);
-        my_rs = (l == k) ? rs : my_rs;
         const T t = a[k] * (rs * rs);
 #pragma unroll
         for (int c = k + 1; c < D; ++c) a[c] = fma(-t, Lc[k * LS + c], a[c]);
         sfence();
     }
     ok = good;
-    return my_rs;
+    const int lc = (l < D) ? l : (D - 1);
+    return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l)
 }
 
-// row l of a packed lower-triangular matrix (zeros beyond the diagonal / for lanes >= D)
+// row l of a packed lower-triangular matrix; entries beyond the diagonal are never consumed
+// (chol16 only publishes and updates entries j <= l), so they are left as whatever was read
 template <class T, int D> UKFB_DEV void load_row(const T* PKS, int l, T (&row)[D]) {
     const int lr = (l < D) ? l : (D - 1);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        const T v = PKS[lr * (lr + 1) / 2 + ((j <= lr) ? j : 0)];
-        row[j] = (l < D && j <= l) ? v : T(0);
-    }
+    for (int j = 0; j < D; ++j) row[j] = PKS[lr * (lr + 1) / 2 + ((j <= lr) ? j : 0)];
 }
 
-// scaled column l of the factor (zeros above the diagonal)
+// scaled column l of the factor (the stored column already has zeros above the diagonal);
+// lanes without a column (l >= D) get zeros through w = 0
 template <class T, int D, int LS> UKFB_DEV void load_column(const T* Lc, int l, T rs, T (&col)[D]) {
     const int lc = (l < D) ? l : (D - 1);
+    const T w = (l < D) ? rs : T(0);
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-        const T v = Lc[lc * LS + c] * rs;
-        col[c] = (c >= l) ? v : T(0);
-    }
+    for (int c = 0; c < D; ++c) col[c] = Lc[lc * LS + c] * w;
 }
 
 // fast boxminus of the SO(3) component only: log(conj(y) * x)
@@ -210,20 +222,17 @@ UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], bool need_q,
 
 // One entry of the shaped process noise R without exec-masked regions (cf. process_noise_entry).
 template <class T, class M>
-UKFB_DEV T process_noise_entry16(const T* Rn, const T* ROT, const KArgs<T>& a, const ProcIn<T>& pin, int r, int c) {
+UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const KArgs<T>& a, const ProcIn<T>& pin, int r,
+                                 int c) {
     constexpr int D = M::D;
-    const T rn = Rn[r * D + c];
-    T vacc = rn;
+    T vacc = T(0);
     if (M::MODEL == 0) {
-        // acceleration branch (PoseUKF.cpp:190-191): raw noise, block(6,6,3,3) = 2 acc.cov
-        const bool vel = (r >= 6 && r < 9 && c >= 6 && c < 9);
-        const int k = vel ? ((r - 6) * 3 + (c - 6)) : 0;
-        T ac = T(0);
-#pragma unroll
-        for (int s = 0; s < 9; ++s) ac = (k == s) ? a.acc_cov[s] : ac;
-        vacc = vel ? T(2) * ac : rn;
+        // acceleration branch (PoseUKF.cpp:190-191): raw noise with block(6,6,3,3) = 2 acc.cov, prepared by
+        // the host (ukf_batch.hip: rebuild_racc) whenever the noise or acc.cov changes
+        vacc = Racc[r * D + c];
         if (__all(pin.use_acc)) return vacc;   // wave-uniform fast path
     }
+    const T rn = Rn[r * D + c];
     const int o = (r < 3 && c < 3) ? 0 : ((r >= 3 && r < 6 && c >= 3 && c < 6) ? 3 : -1);
     const int oo = o < 0 ? 0 : o;
     const int rr = (o < 0) ? 0 : (r - oo), cc = (o < 0) ? 0 : (c - oo);
@@ -379,6 +388,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
             for (int s = 0; s < S; ++s) xp[s] = has_ctr ? ref[s] : xp[s];
             const bool has_p = has_pair || has_ctr, has_m = has_pair;
+            const T wp = has_p ? T(1) : T(0), wm = has_m ? T(1) : T(0);
 
             // ---- ukfom meanSigmaPoints, first iteration over the whole tangent (reference = centre)
             sfence();
@@ -393,12 +403,12 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     rot_minus(qp, qr, rp);
                     rot_minus(qm, qr, rm);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) loc[RT + k] = (has_p ? rp[k] : T(0)) + (has_m ? rm[k] : T(0));
+                    for (int k = 0; k < 3; ++k) loc[RT + k] = fma(wm, rm[k], wp * rp[k]);
                 }
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if (s < Q) loc[s] = (has_p ? xp[s] - ref[s] : T(0)) + (has_m ? xm[s] - ref[s] : T(0));
-                    else if (s >= Q + 4) loc[s - 1] = (has_p ? xp[s] - ref[s] : T(0)) + (has_m ? xm[s] - ref[s] : T(0));
+                    if (s < Q) loc[s] = fma(wm, xm[s] - ref[s], wp * (xp[s] - ref[s]));
+                    else if (s >= Q + 4) loc[s - 1] = fma(wm, xm[s] - ref[s], wp * (xp[s] - ref[s]));
                 }
                 T md[D];
 #pragma unroll
@@ -459,7 +469,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     T m2 = T(0);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const T loc = (has_p ? rp[k] : T(0)) + (has_m ? rm[k] : T(0));
+                        const T loc = fma(wm, rm[k], wp * rp[k]);
                         mr[k] = row_allreduce(loc) * (T(1) / T(N));
                         m2 += mr[k] * mr[k];
                     }
@@ -542,7 +552,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #ifdef X_NO_NOISE
                     const T val = T(0.5) * acc[i2][j2];
 #else
-                    const T val = fma(T(0.5), acc[i2][j2], process_noise_entry16<T, M>(Rn, ROT, a, pin, rc, cc));
+                    const T val = fma(T(0.5), acc[i2][j2], process_noise_entry16<T, M>(Rn, a.Racc + fc * a.Rn_stride, ROT, a, pin, rc, cc));
 #endif
                     PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = val;
                 }
@@ -606,24 +616,44 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             bool ok1;
             T rs;
-            T zp[4], zm[4], z0[4];
+            T zp[4] = {T(0), T(0), T(0), T(0)}, zm[4] = {T(0), T(0), T(0), T(0)}, z0[4] = {T(0), T(0), T(0), T(0)};
             {
-                T mu_r[S];
+                T arow[D];
+                load_row<T, D>(PKS, l, arow);
+                rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, ok1);
+                wsync();
+            }
+            if (MT<M>::HAS_EUCLID_MEAS) {
+                // sub-state selections (PoseUKF.cpp:7-26,35-69): Z = mu[sel] +- L[sel][l], read by index from LDS
+                const int lc = has_pair ? l : (D - 1);
+                const T w = has_pair ? rs : T(0);
+                const unsigned long long sel[3] = {MT<M>::SEL0, MT<M>::SEL1, MT<M>::SEL2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int sk = int((sel[k] >> (4 * midc)) & 15ull);
+                    const bool used = sk != 15;
+                    const int si = used ? sk : 0;
+                    const int ti = (si < Q) ? si : (si - 1);
+                    const T m0 = used ? MUS[si] : T(0);
+                    const T cv = used ? Lc[lc * LS + ti] * w : T(0);
+                    zp[k] = m0 + cv; zm[k] = m0 - cv; z0[k] = m0;
+                }
+            }
+            if (__any(need_q)) {   // wave-uniform: measurement models that read the orientation
+                T mu_r[S], col[D], xp[S], xm[S], gp[4], gm[4], g0[4];
 #pragma unroll
                 for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
-                {
-                    T arow[D];
-                    load_row<T, D>(PKS, l, arow);
-                    rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, ok1);
-                    wsync();
-                }
-                T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
-                T xp[S], xm[S];
-                sigma_pair<T, M>(mu_r, col, __any(need_q), xp, xm);
-                M::measure(xp, midc, zp);
-                M::measure(xm, midc, zm);
-                M::measure(mu_r, midc, z0);
+                sigma_pair<T, M>(mu_r, col, true, xp, xm);
+                MT<M>::gen_measure(xp, gp);
+                MT<M>::gen_measure(xm, gm);
+                MT<M>::gen_measure(mu_r, g0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    zp[k] = need_q ? gp[k] : zp[k];
+                    zm[k] = need_q ? gm[k] : zm[k];
+                    z0[k] = need_q ? g0[k] : z0[k];
+                }
             }
             sfence();
             // ---- mean of Z.  Euclidean: one pass is exact.  SO(3): iterate on the manifold.
@@ -713,8 +743,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             T cx[3] = {T(0), T(0), T(0)};
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const T lv = Lc[j * LS + la];
-                const T v = (j <= la) ? lv : T(0);
+                const T v = Lc[j * LS + la];   // zero for j > la
 #pragma unroll
                 for (int k = 0; k < 3; ++k) cx[k] = fma(v, WK[j * 4 + k], cx[k]);
                 if ((j & 3) == 3) sfence();
@@ -767,10 +796,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 const int lc = has_pair ? l : (D - 1);
                 T c3[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T v = Lc[lc * LS + RT + k] * rs2;
-                    c3[k] = (RT + k >= l) ? v : T(0);
-                }
+                for (int k = 0; k < 3; ++k) c3[k] = Lc[lc * LS + RT + k] * (has_pair ? rs2 : T(0));
                 const T v0[3] = {d0[RT], d0[RT + 1], d0[RT + 2]};
                 const T vp[3] = {v0[0] + c3[0], v0[1] + c3[1], v0[2] + c3[2]};
                 const T vm[3] = {v0[0] - c3[0], v0[1] - c3[1], v0[2] - c3[2]};
@@ -799,8 +825,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             T cr[3] = {T(0), T(0), T(0)};
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const T lv = Lc[j * LS + la];
-                const T v = (j <= la) ? lv : T(0);
+                const T v = Lc[j * LS + la];   // zero for j > la
 #pragma unroll
                 for (int k = 0; k < 3; ++k) cr[k] = fma(v, WK[j * 4 + k], cr[k]);
                 if ((j & 3) == 3) sfence();

@@ -7,6 +7,7 @@ The directory name carries a hyphen, so import it through the repo-root shim:
     import slam_pose_estimation_amd as spe
 """
 from . import synth  # noqa: F401
+from .sharding import gather_means, shard_range  # noqa: F401
 from .build import build_engine  # noqa: F401
 from .engine import *  # noqa: F401,F403
 from .engine import BatchOrientationUKF, BatchPoseUKF, BatchUKF, Config, UkfbError, load_library  # noqa: F401

@@ -1,3 +1,4 @@
+import torch  # noqa: F401  (must load before the engine library: one HIP runtime per process)
 import os
 import sys
 

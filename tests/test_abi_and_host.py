@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/ukf_batch.h declares (no compute call is made without a GPU), and fails loudly -- never
+falls back to a CPU path -- when no HIP device is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ukf_batch.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ukfb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_the_same_entry_points(spe):
+    assert header_symbols() == sorted(spe.engine.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(spe):
+    lib = spe.load_library()
+    missing = [s for s in header_symbols() if not hasattr(lib, s)]
+    assert missing == []
+
+
+def test_default_config_matches_reference_defaults(spe):
+    import ctypes as C
+    lib = spe.load_library()
+    c = spe.Config()
+    assert lib.ukfb_default_config(C.byref(c)) == 0
+    assert c.mean_tol == 1e-6                      # ukfom meanSigmaPoints
+    assert c.min_time_delta == 1.0e-9              # UnscentedKalmanFilter.hpp:31
+    assert c.max_time_delta == np.finfo(np.float64).max   # UnscentedKalmanFilter.hpp:32
+    assert c.gate_chi2 < 0                         # accept_any_mahalanobis_distance
+    assert c.lanes_per_filter == 16
+
+
+def test_status_bits_agree_between_engine_binding_and_oracle(spe, onp):
+    for name in ("ST_SKIPPED_FIRST_TS", "ST_SKIPPED_SMALL_DT", "ST_ERR_NEG_DT", "ST_ERR_DT_TOO_LARGE",
+                 "ST_ERR_NONFINITE_MEAS", "ST_ERR_CHOLESKY", "ST_WARN_MEAN_NOCONV", "ST_UNINITIALISED", "ST_INACTIVE",
+                 "ST_REJECTED_GATE"):
+        assert getattr(spe, name) == getattr(onp, name)
+    text = open(os.path.join(ROOT, "include", "ukf_batch.h")).read()
+    for name, bit in re.findall(r"UKFB_(ST_[A-Z_]+) = 1u << (\d+)", text):
+        assert getattr(spe, name) == 1 << int(bit)
+    for name, val in re.findall(r"UKFB_(MEAS_[A-Z0-9_]+) = (-?\d+)", text):
+        assert getattr(spe, name) == int(val)
+
+
+def test_engine_refuses_to_run_without_a_gpu(spe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(spe.UkfbError) as ei:
+        spe.BatchPoseUKF(8)
+    assert "no usable HIP device" in str(ei.value)
+
+
+def test_missing_library_is_a_loud_error(spe, monkeypatch, tmp_path):
+    monkeypatch.setattr(spe.engine, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(spe.engine, "_lib", None)
+    with pytest.raises(spe.UkfbError):
+        spe.load_library()
+
+
+def test_shard_ranges_partition_the_batch(spe):
+    for total in (0, 1, 7, 1_048_576, 1_000_003):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                first, count = spe.shard_range(total, world, r)
+                assert first == nxt and count >= 0
+                nxt = first + count
+            assert nxt == total
+    assert spe.shard_range(1_048_576, 8, 3) == (393216, 131072)
+
+
+def test_synthetic_inputs_are_counter_based(spe):
+    """Any shard regenerates exactly the slice of the full batch (SplitMix64 keyed by filter id)."""
+    mu, cov = spe.synth.pose_initial(64)
+    mu2, cov2 = spe.synth.pose_initial(16, first=24)
+    assert np.array_equal(mu[24:40], mu2) and np.array_equal(cov[24:40], cov2)
+    assert np.abs(np.linalg.norm(mu[:, 3:7], axis=1) - 1).max() < 1e-15
+    assert (np.linalg.eigvalsh(cov) > 0).all() and np.array_equal(cov, np.swapaxes(cov, 1, 2))
+    a1 = spe.synth.pose_cycle_inputs(8, 5, first=100)[0]
+    a2 = spe.synth.pose_cycle_inputs(32, 5, first=92)[0][8:16]
+    assert np.array_equal(a1, a2)

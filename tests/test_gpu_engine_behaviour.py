@@ -1,0 +1,235 @@
+"""GPU tests of the engine's behaviour around the arithmetic: committed golden fixtures through the
+C-ABI, the time gate (UnscentedKalmanFilter.hpp:83-125), mahalanobis gating, failure statuses,
+device-pointer entry points, and size-independent properties at BASELINE.json's full batch sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import max_abs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = {0: 1e-9, 1: 1e-4}
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_golden_pose_steps_through_the_c_abi(spe, prec):
+    g = load("pose_steps.npz")
+    n = g["mu"].shape[0]
+
+    def fresh():
+        e = spe.BatchPoseUKF(n, precision=prec)
+        e.set_process_noise(g["R"])
+        e.initialize(g["mu"], g["cov"])
+        return e
+    e = fresh(); e.set_acceleration(g["acc"], g["acc_cov"]); e.predict(float(g["dt"]))
+    m, c, _ = e.state()
+    assert max_abs(m, g["pred_acc_mu"]) <= TOL[prec] and max_abs(c, g["pred_acc_cov"]) <= TOL[prec]
+    e = fresh(); e.predict(float(g["dt"]))    # acceleration never set: NaN default -> constant velocity
+    m, c, _ = e.state()
+    assert max_abs(m, g["pred_cv_mu"]) <= TOL[prec] and max_abs(c, g["pred_cv_cov"]) <= TOL[prec]
+    for model in range(9):
+        e = fresh(); e.update(model, g[f"z_{model}"], g["Q"])
+        m, c, _ = e.state()
+        assert e.status_summary() == 0
+        assert max_abs(m, g[f"upd_{model}_mu"]) <= TOL[prec] and max_abs(c, g[f"upd_{model}_cov"]) <= TOL[prec]
+
+
+def test_golden_trajectory_and_orientation_fixtures(spe):
+    g = load("pose_trajectory.npz")
+    n = g["mu0"].shape[0]
+    e = spe.BatchPoseUKF(n); e.set_process_noise(g["R"]); e.initialize(g["mu0"], g["cov0"])
+    for k in range(int(g["cycles"])):
+        e.set_acceleration(g["acc"][k], g["acc_cov"])
+        e.cycle(float(g["dt"]), spe.MEAS_POS3, g["z"][k], g["Q"])
+    m, c, _ = e.state()
+    assert e.status_summary() == 0
+    assert max_abs(m, g["mu_final"]) <= 1e-9 and max_abs(c, g["cov_final"]) <= 1e-9
+    o = load("orient_steps.npz")
+    tau = float(o["tau"])
+    eo = spe.BatchOrientationUKF(o["mu"].shape[0], tau, tau, spe.synth.ORIENT_LATITUDE)
+    assert max_abs(eo.earth_rotation, o["earth"]) == 0
+    eo.initialize(o["mu"], o["cov"]); eo.set_process_noise(o["R"]); eo.set_orient_inputs(o["gyro"], o["acc"])
+    eo.predict(float(o["dt"])); m, c, _ = eo.state()
+    assert max_abs(m, o["pred_mu"]) <= 1e-9 and max_abs(c, o["pred_cov"]) <= 1e-9
+    eo.update(spe.MEAS_ORIENT_BODYVEL3, o["z"], o["Q"]); m, c, _ = eo.state()
+    assert max_abs(m, o["upd_mu"]) <= 1e-9 and max_abs(c, o["upd_cov"]) <= 1e-9
+    assert max_abs(eo.rotation_rate(), o["rotation_rate"]) <= 1e-9
+
+
+def test_timestamp_gate_per_filter(spe, oracle, onp):
+    """predictionStepFromSampleTime per filter: first call latches, small dt skips, negative / too large
+    dt are errors that leave the state alone, last time advances iff dt > min (hpp:83-125)."""
+    n = 8
+    mu, cov = spe.synth.pose_initial(n)
+    e = spe.BatchPoseUKF(n); e.initialize(mu, cov); e.configure(max_time_delta=10.0)
+    last = np.array([0, 0, 5_000_000, 5_000_000, 5_000_000, 5_000_000, 5_000_000, 5_000_000], dtype=np.int64)
+    e.set_last_measurement_time(last)
+    ts = np.array([1_000_000, 7, 5_010_000, 5_000_000, 4_000_000, 16_000_000, 5_500_000, 5_000_001], dtype=np.int64)
+    e.predict_timestamps(ts)
+    st = e.status()
+    new_last, dt, st_o = oracle.gate_timestamps(ts, last, 1e-9, 10.0)
+    assert (st == st_o).all()
+    assert list(st) == [onp.ST_SKIPPED_FIRST_TS, onp.ST_SKIPPED_FIRST_TS, 0, onp.ST_SKIPPED_SMALL_DT,
+                        onp.ST_ERR_NEG_DT, onp.ST_ERR_DT_TOO_LARGE, 0, 0]
+    assert (e.last_measurement_time() == new_last).all()
+    m, c, _ = e.state()
+    run = st == 0
+    m_o, c_o, _ = oracle.pose_predict(mu[run], cov[run], spe.synth.pose_default_process_noise(), None, None, dt[run])
+    assert max_abs(m[run], m_o) <= 1e-9 and max_abs(c[run], c_o) <= 1e-9
+    assert max_abs(m[~run], mu[~run]) == 0 and max_abs(c[~run], cov[~run]) == 0
+    # per-filter dt array takes the same gate
+    e2 = spe.BatchPoseUKF(n); e2.initialize(mu, cov)
+    dts = np.array([0.01, 0.0, -1.0, 1e-10, 0.5, 0.02, 0.03, 1.0])
+    e2.predict(dts)
+    assert list(e2.status()) == [0, onp.ST_SKIPPED_SMALL_DT, onp.ST_ERR_NEG_DT, onp.ST_SKIPPED_SMALL_DT, 0, 0, 0, 0]
+
+
+def test_fused_cycle_with_gated_predict_and_masked_update(spe, oracle, onp):
+    """In one fused launch some filters skip the predict (tiny dt -> whole batch here), others skip the
+    update (model id -1); each must equal the matching sequence of reference calls."""
+    import torch
+    n = 37
+    mu, cov = spe.synth.pose_initial(n)
+    acc, z, Q = spe.synth.pose_cycle_inputs(n, 0, mu[:, :3])
+    models = spe.synth.pose_mixed_models(n, 3)
+    zz = spe.synth.pose_measurement_for_model(mu, models, z - mu[:, :3])
+    R = spe.synth.pose_default_process_noise()
+    acc_cov = 0.01 * np.eye(3)
+    e = spe.BatchPoseUKF(n); e.initialize(mu, cov); e.set_acceleration(acc, acc_cov)
+    zt = torch.from_numpy(zz).cuda(); Qt = torch.from_numpy(Q.reshape(n, 9)).cuda()
+    mt = torch.from_numpy(models).cuda()
+    e.cycle_dev(0.01, 0, zt, Qt, meas_model_dev=mt)
+    m, c, _ = e.state(); st = e.status()
+    m_o, c_o, _ = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
+    m_o, c_o, st_o = oracle.pose_update(m_o, c_o, models, zz, Q)
+    assert (st == st_o).all() and (models < 0).any()
+    assert max_abs(m, m_o) <= 1e-9 and max_abs(c, c_o) <= 1e-9
+    # predict gated off for everyone (dt below min_time_delta): the update still runs on the old state
+    e2 = spe.BatchPoseUKF(n); e2.initialize(mu, cov); e2.set_acceleration(acc, acc_cov)
+    e2.cycle(1e-12, spe.MEAS_POS3, z, Q)
+    m2, c2, _ = e2.state()
+    m_u, c_u, _ = oracle.pose_update(mu, cov, 0, z, Q)
+    assert (e2.status() == onp.ST_SKIPPED_SMALL_DT).all()
+    assert max_abs(m2, m_u) <= 1e-9 and max_abs(c2, c_u) <= 1e-9
+    # negative dt is the reference's exception: neither predict nor update touches the filter
+    e3 = spe.BatchPoseUKF(n); e3.initialize(mu, cov)
+    e3.cycle(-0.5, spe.MEAS_POS3, z, Q)
+    m3, c3, _ = e3.state()
+    assert ((e3.status() & onp.ST_ERR_NEG_DT) != 0).all() and max_abs(m3, mu) == 0 and max_abs(c3, cov) == 0
+
+
+def test_mahalanobis_gate(spe, oracle, onp):
+    n = 64
+    mu, cov = spe.synth.pose_initial(n)
+    _, z, Q = spe.synth.pose_cycle_inputs(n, 0, mu[:, :3])
+    z[::2] += 3.0   # gross outliers on every other filter
+    e = spe.BatchPoseUKF(n, gate_chi2=7.81); e.initialize(mu, cov)
+    e.update(spe.MEAS_POS3, z, Q)
+    st = e.status()
+    m_o, c_o, st_o = oracle.pose_update(mu, cov, 0, z, Q, cfg=oracle.default_config(gate_chi2=7.81))
+    assert (st == st_o).all() and ((st & onp.ST_REJECTED_GATE) != 0)[::2].all() and (st[1::2] == 0).all()
+    m, c, _ = e.state()
+    assert max_abs(m, m_o) <= 1e-9 and max_abs(c, c_o) <= 1e-9
+    assert max_abs(m[::2], mu[::2]) == 0
+
+
+def test_failure_statuses_leave_the_filter_untouched(spe, onp):
+    n = 6
+    mu, cov = spe.synth.pose_initial(n)
+    bad = cov.copy(); bad[2, 5, 5] = -1.0            # not positive definite
+    e = spe.BatchPoseUKF(n); e.initialize(mu[:5], bad[:5])      # filter 5 never initialised
+    e.predict(0.01)
+    st = e.status()
+    assert st[2] == onp.ST_ERR_CHOLESKY and st[5] == onp.ST_UNINITIALISED and (st[[0, 1, 3, 4]] == 0).all()
+    m, c, init = e.state()
+    assert list(init) == [True] * 5 + [False]
+    assert max_abs(m[2], mu[2]) == 0 and max_abs(c[2], 0.5 * (bad[2] + bad[2].T)) == 0
+    assert e.status_summary() == (onp.ST_ERR_CHOLESKY | onp.ST_UNINITIALISED)
+    _, z, Q = spe.synth.pose_cycle_inputs(n, 0, mu[:, :3])
+    e.update(spe.MEAS_POS3, z, Q)
+    assert e.status()[2] == onp.ST_ERR_CHOLESKY and e.status()[5] == onp.ST_UNINITIALISED
+    # Orientation filter: non-finite measurement is rejected (OrientationUKF.cpp:67), the state stays
+    s = spe.synth
+    mo, co = s.orient_initial(4)
+    eo = spe.BatchOrientationUKF(4, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE); eo.initialize(mo, co)
+    zz = np.zeros((4, 3)); zz[1, 2] = np.nan
+    QQ = np.stack([np.eye(3) * 0.01] * 4); QQ[3, 0, 0] = np.inf
+    eo.update(spe.MEAS_ORIENT_BODYVEL3, zz, QQ)
+    sto = eo.status()
+    assert sto[1] == onp.ST_ERR_NONFINITE_MEAS and sto[3] == onp.ST_ERR_NONFINITE_MEAS and sto[0] == 0 and sto[2] == 0
+    m2, c2, _ = eo.state()
+    assert max_abs(m2[[1, 3]], mo[[1, 3]]) == 0
+    with pytest.raises(spe.UkfbError):
+        eo.update(spe.MEAS_POS3, zz, QQ)          # Pose model id on an Orient engine
+    with pytest.raises(spe.UkfbError):
+        spe.BatchPoseUKF(4, lanes_per_filter=48)  # only 16 / 32 / 64
+
+
+def test_per_filter_process_noise_and_read_back(spe, oracle):
+    n = 9
+    mu, cov = spe.synth.pose_initial(n)
+    rng = np.random.default_rng(0)
+    R = np.stack([np.diag(rng.uniform(1e-4, 1e-2, 12)) for _ in range(n)])
+    e = spe.BatchPoseUKF(n); e.initialize(mu, cov)
+    assert max_abs(e.process_noise(0), spe.synth.pose_default_process_noise()) == 0   # PoseUKF.cpp:103-107
+    e.set_process_noise(R, first=0)
+    assert max_abs(e.process_noise(4), R[4]) == 0
+    e.predict(0.02)
+    m, c, _ = e.state()
+    m_o, c_o, _ = oracle.pose_predict(mu, cov, R, None, None, 0.02)
+    assert max_abs(m, m_o) <= 1e-9 and max_abs(c, c_o) <= 1e-9
+
+
+@pytest.mark.parametrize("prec,n", [(0, 65536), (1, 1048576)])
+def test_full_size_properties(spe, prec, n):
+    """BASELINE configs 2 (65 536 fp64) and 3 (1 048 576 fp32): properties that need no oracle run.
+    (a) a batch equals its two halves run separately, bit for bit (no coupling between filters, ragged
+    tail handled); (b) covariances stay symmetric positive definite, quaternions unit; (c) an update
+    with an uninformative measurement (Q -> huge) is the identity."""
+    import torch
+    CH = 131072
+    dev = torch.device("cuda")
+    tdt = torch.float64 if prec == 0 else torch.float32
+    full = spe.BatchPoseUKF(n, precision=prec)
+    half_a = spe.BatchPoseUKF(n // 2 + 3, precision=prec)
+    half_b = spe.BatchPoseUKF(n - (n // 2 + 3), precision=prec)
+    acc_t, z_t, Q_t = (torch.empty((n, k), dtype=tdt, device=dev) for k in (3, 3, 9))
+    for lo in range(0, n, CH):
+        hi = min(n, lo + CH)
+        mu, cov = spe.synth.pose_initial(hi - lo, first=lo)
+        acc, z, Q = spe.synth.pose_cycle_inputs(hi - lo, 0, mu[:, :3], first=lo)
+        full.initialize(mu, cov, first=lo)
+        acc_t[lo:hi] = torch.from_numpy(acc).to(dev, tdt); z_t[lo:hi] = torch.from_numpy(z).to(dev, tdt)
+        Q_t[lo:hi] = torch.from_numpy(Q.reshape(-1, 9)).to(dev, tdt)
+    split = n // 2 + 3
+    for eng, lo, hi in ((half_a, 0, split), (half_b, split, n)):
+        for a in range(lo, hi, CH):
+            b = min(hi, a + CH)
+            mu, cov = spe.synth.pose_initial(b - a, first=a)
+            eng.initialize(mu, cov, first=a - lo)
+    acc_cov = 0.01 * np.eye(3)
+    for eng, lo, hi in ((full, 0, n), (half_a, 0, split), (half_b, split, n)):
+        eng.set_acceleration(None, acc_cov)
+        eng.bind_acceleration_dev(acc_t[lo:hi].contiguous())
+        for _ in range(3):
+            eng.cycle_dev(0.01, spe.MEAS_POS3, z_t[lo:hi].contiguous(), Q_t[lo:hi].contiguous())
+        assert eng.status_summary() == 0
+    sel = np.concatenate([np.arange(0, 2048), np.arange(split - 1024, split + 1024), np.arange(n - 2048, n)])
+    m_f, c_f, _ = full.state()
+    m_a, c_a, _ = half_a.state(); m_b, c_b, _ = half_b.state()
+    assert np.array_equal(m_f, np.concatenate([m_a, m_b])) and np.array_equal(c_f, np.concatenate([c_a, c_b]))
+    assert np.isfinite(m_f).all() and np.isfinite(c_f).all()
+    assert np.abs(np.linalg.norm(m_f[:, 3:7], axis=1) - 1).max() < (1e-12 if prec == 0 else 1e-5)
+    assert (np.linalg.eigvalsh(c_f[sel]) > 0).all()
+    # uninformative measurement: identity up to rounding
+    big = torch.eye(3, dtype=tdt, device=dev).reshape(1, 9).repeat(n, 1) * 1e12
+    full.update_dev(spe.MEAS_POS3, z_t, big)
+    m_i, c_i, _ = full.state()
+    tol = 1e-8 if prec == 0 else 1e-4
+    assert max_abs(m_i[sel], m_f[sel]) < tol and max_abs(c_i[sel], c_f[sel]) < tol

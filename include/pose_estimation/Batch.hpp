@@ -1,0 +1,101 @@
+// pose_estimation/Batch.hpp -- batched C++ siblings of PoseUKF / OrientationUKF: one object owns N
+// filters resident on one MI355X.  Thin RAII over include/ukf_batch.h; arrays are AoS doubles in the
+// layouts documented there.  This is the interface the engine is built for (a Rock component that
+// tracks N hypotheses / particles / vehicles calls these instead of N scalar objects).
+#ifndef _POSE_ESTIMATION_BATCH_HPP
+#define _POSE_ESTIMATION_BATCH_HPP
+
+#include <ukf_batch.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace pose_estimation
+{
+
+class BatchUKF
+{
+public:
+    BatchUKF(int model, int precision, int64_t capacity, int device = 0, void* hip_stream = NULL) : engine(NULL)
+    {
+        if (ukfb_create(&engine, model, precision, capacity, device, hip_stream) != UKFB_OK)
+            throw std::runtime_error(std::string("pose_estimation: MI355X engine unavailable: ") + ukfb_last_error());
+        ukfb_describe(engine, NULL, NULL, &cap, &S, &D, &PK);
+    }
+    virtual ~BatchUKF() { ukfb_destroy(engine); }
+
+    int64_t capacity() const { return cap; }
+    int storedSize() const { return S; }
+    int dof() const { return D; }
+    ukfb_engine* handle() { return engine; }
+
+    /** initializeFilter for filters [first, first + count) */
+    void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov) { check(ukfb_initialize(engine, first, count, mu, cov)); }
+    /** getCurrentState for filters [first, first + count); cov may be NULL */
+    void getCurrentStates(int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised = NULL) { check(ukfb_get_state(engine, first, count, mu, cov, initialised)); }
+    void setProcessNoiseCovariance(const double* R) { check(ukfb_set_process_noise(engine, R)); }
+    void setProcessNoiseCovariances(int64_t first, int64_t count, const double* R) { check(ukfb_set_process_noise_per_filter(engine, first, count, R)); }
+    void setLastMeasurementTimes(int64_t first, int64_t count, const int64_t* t_us) { check(ukfb_set_last_measurement_time(engine, first, count, t_us)); }
+    void setTimeDeltas(double min_dt, double max_dt)
+    {
+        ukfb_config c; ukfb_get_config(engine, &c); c.min_time_delta = min_dt; c.max_time_delta = max_dt; check(ukfb_set_config(engine, &c));
+    }
+    /** predictionStep(delta_t) for every filter; per-filter outcomes in status() */
+    void predictionStep(double delta_t) { check(ukfb_predict(engine, delta_t)); }
+    void predictionSteps(const double* delta_t) { check(ukfb_predict_dt(engine, delta_t)); }
+    /** predictionStepFromSampleTime(ts[i]) per filter (int64 microseconds) */
+    void predictionStepsFromSampleTimes(const int64_t* ts_us) { check(ukfb_predict_timestamps(engine, ts_us)); }
+    /** integrateMeasurement with one model id (UKFB_MEAS_*) for the batch */
+    void integrateMeasurements(int model, const double* z, const double* Q, const uint8_t* active = NULL) { check(ukfb_update(engine, model, z, Q, active)); }
+    /** per-filter model ids (negative = none): the asynchronous mixed stream of BASELINE config 5 */
+    void integrateMixedMeasurements(const int32_t* model, const double* z, const double* Q) { check(ukfb_update_mixed(engine, model, z, Q)); }
+    /** fused predictionStep + integrateMeasurement in one launch */
+    void cycle(double delta_t, int model, const double* z, const double* Q) { check(ukfb_cycle(engine, delta_t, model, z, Q)); }
+    std::vector<uint32_t> status()
+    {
+        std::vector<uint32_t> st(static_cast<size_t>(cap), 0u);
+        check(ukfb_get_status(engine, 0, cap, st.data()));
+        return st;
+    }
+    void sync() { check(ukfb_sync(engine)); }
+
+protected:
+    void check(int rc) const { if (rc != UKFB_OK) throw std::runtime_error(std::string("pose_estimation engine: ") + ukfb_last_error()); }
+    ukfb_engine* engine;
+    int64_t cap;
+    int S, D, PK;
+
+private:
+    BatchUKF(const BatchUKF&);
+    BatchUKF& operator=(const BatchUKF&);
+};
+
+class BatchPoseUKF : public BatchUKF
+{
+public:
+    BatchPoseUKF(int64_t capacity, int precision = UKFB_F64, int device = 0) : BatchUKF(UKFB_MODEL_POSE, precision, capacity, device)
+    {
+        double R[144] = {0};   // PoseUKF.cpp:103-107
+        for (int k = 0; k < 3; ++k) { R[k * 13] = 0.01; R[(3 + k) * 13] = 0.001; R[(6 + k) * 13] = 0.00001; R[(9 + k) * 13] = 0.00001; }
+        setProcessNoiseCovariance(R);
+    }
+    /** integrateMeasurement(AccelerationMeasurement) per filter; NaN row = none (PoseUKF.cpp:109,175-178) */
+    void setAccelerations(int64_t first, int64_t count, const double* acc_mu, const double* acc_cov3x3) { check(ukfb_pose_set_acceleration(engine, first, count, acc_mu, acc_cov3x3)); }
+};
+
+class BatchOrientationUKF : public BatchUKF
+{
+public:
+    BatchOrientationUKF(int64_t capacity, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3], int precision = UKFB_F64, int device = 0)
+        : BatchUKF(UKFB_MODEL_ORIENT, precision, capacity, device)
+    {
+        check(ukfb_orient_set_params(engine, gyro_bias_tau, acc_bias_tau, earth_rotation));
+    }
+    void setInputs(int64_t first, int64_t count, const double* gyro, const double* acc) { check(ukfb_orient_set_inputs(engine, first, count, gyro, acc)); }
+    void getRotationRates(int64_t first, int64_t count, double* out) { check(ukfb_orient_get_rotation_rate(engine, first, count, out)); }
+};
+
+}
+
+#endif

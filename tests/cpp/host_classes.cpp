@@ -1,0 +1,94 @@
+// Drives the host C++ mirror (include/pose_estimation/...) the way a Rock component drives the reference
+// classes and prints the resulting state as one JSON object; tests/test_gpu_host_cpp.py compares it
+// with the CPU oracle.  Inputs are fixed constants so both sides can restate them.
+#include <pose_estimation/orientation_estimator/OrientationUKF.hpp>
+#include <pose_estimation/pose_with_velocity/PoseUKF.hpp>
+
+#include <cstdio>
+
+using namespace pose_estimation;
+
+static void print_state(const char* name, const double* mu, int S, const double* cov, int D, bool last)
+{
+    std::printf("\"%s\": {\"mu\": [", name);
+    for (int i = 0; i < S; ++i) std::printf("%s%.17g", i ? ", " : "", mu[i]);
+    std::printf("], \"cov\": [");
+    for (int i = 0; i < D * D; ++i) std::printf("%s%.17g", i ? ", " : "", cov[i]);
+    std::printf("]}%s\n", last ? "" : ",");
+}
+
+int main()
+{
+    // ---------------- PoseUKF
+    PoseWithVelocity x0;
+    x0.position[0] = 1.0; x0.position[1] = -2.0; x0.position[2] = 0.5;
+    x0.orientation = Quaterniond(0.9238795325112867, 0.0, 0.3826834323650898, 0.0);   // 45 deg about y
+    x0.velocity[0] = 0.3; x0.velocity[1] = 0.1; x0.velocity[2] = -0.2;
+    x0.angular_velocity[0] = 0.05; x0.angular_velocity[1] = -0.02; x0.angular_velocity[2] = 0.1;
+    PoseUKF::Covariance P0 = PoseUKF::Covariance::Zero();
+    for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) P0(i, j) = (i == j ? 0.04 : 0.0) + 0.001 / (1.0 + i + j);
+    PoseUKF f(x0, P0);
+    bool threw_negative = false;
+    f.predictionStepFromSampleTime(base::Time::fromMicroseconds(1000000));   // first call: latch only
+    f.predictionStepFromSampleTime(base::Time::fromMicroseconds(1020000));   // dt = 0.02, constant velocity
+    PoseUKF::AccelerationMeasurement acc;
+    acc.mu[0] = 0.2; acc.mu[1] = -0.1; acc.mu[2] = 0.05;
+    acc.cov = 0.01 * PoseUKF::AccelerationMeasurement::Cov::Identity();
+    f.integrateMeasurement(acc);
+    f.predictionStepFromSampleTime(base::Time::fromMicroseconds(1030000));   // dt = 0.01, acceleration branch
+    try { f.predictionStepFromSampleTime(base::Time::fromMicroseconds(1000000)); } catch (const std::runtime_error&) { threw_negative = true; }
+    PoseUKF::PositionMeasurement zp;
+    zp.mu[0] = 1.02; zp.mu[1] = -1.97; zp.mu[2] = 0.49;
+    zp.cov = 0.0025 * PoseUKF::PositionMeasurement::Cov::Identity();
+    f.integrateMeasurement(zp);
+    PoseUKF::XVelYawVelMeasurement zv;
+    zv.mu[0] = 0.31; zv.mu[1] = 0.09;
+    zv.cov = 0.01 * PoseUKF::XVelYawVelMeasurement::Cov::Identity();
+    f.integrateMeasurement(zv);
+    PoseUKF::OrientationMeasurement zo;
+    zo.mu[0] = 0.01; zo.mu[1] = 0.79; zo.mu[2] = -0.02;
+    zo.cov = 0.001 * PoseUKF::OrientationMeasurement::Cov::Identity();
+    f.integrateMeasurement(zo);
+    PoseWithVelocity x; PoseUKF::Covariance P;
+    bool ok = f.getCurrentState(x, P);
+    double mu[13]; x.toArray(mu);
+    std::printf("{\"pose_ok\": %s, \"threw_negative\": %s, \"state_size\": %u,\n", ok ? "true" : "false", threw_negative ? "true" : "false", f.getStateSize());
+    print_state("pose", mu, 13, P.data(), 12, false);
+
+    // ---------------- OrientationUKF
+    OrientationState o0;
+    o0.orientation = Quaterniond(0.9914448613738104, 0.0, 0.0, 0.13052619222005157);    // 15 deg yaw
+    o0.velocity[0] = 0.1; o0.velocity[1] = 0.0; o0.velocity[2] = -0.05;
+    o0.bias_gyro[0] = 1e-4; o0.bias_gyro[1] = -2e-4; o0.bias_gyro[2] = 5e-5;
+    o0.bias_acc[0] = 1e-3; o0.bias_acc[1] = 2e-3; o0.bias_acc[2] = -1e-3;
+    o0.gravity(0) = 9.81;
+    OrientationUKF::Covariance Q0 = OrientationUKF::Covariance::Zero();
+    const double sd[13] = {0.05, 0.05, 0.05, 0.1, 0.1, 0.1, 1e-3, 1e-3, 1e-3, 1e-2, 1e-2, 1e-2, 1e-2};
+    for (int i = 0; i < 13; ++i) Q0(i, i) = sd[i] * sd[i];
+    LocationConfiguration loc; loc.latitude = 0.92698121; loc.longitude = 0.15; loc.altitude = 10.0;
+    OrientationUKF g(o0, Q0, 3600.0, 1800.0, loc);
+    OrientationUKF::Covariance Rn = OrientationUKF::Covariance::Zero();
+    const double rn[13] = {1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4, 1e-10, 1e-10, 1e-10, 1e-8, 1e-8, 1e-8, 1e-12};
+    for (int i = 0; i < 13; ++i) Rn(i, i) = rn[i];
+    g.setProcessNoiseCovariance(Rn);
+    OrientationUKF::RotationRate w; w.mu[0] = 0.01; w.mu[1] = -0.02; w.mu[2] = 0.15;
+    OrientationUKF::Acceleration a; a.mu[0] = 0.1; a.mu[1] = -0.05; a.mu[2] = 9.79;
+    g.integrateMeasurement(w);
+    g.integrateMeasurement(a);
+    g.predictionStep(0.01);
+    OrientationUKF::VelocityMeasurement vz; vz.mu[0] = 0.09; vz.mu[1] = 0.03; vz.mu[2] = -0.04;
+    vz.cov = 0.0025 * OrientationUKF::VelocityMeasurement::Cov::Identity();
+    g.integrateMeasurement(vz);
+    bool threw_nonfinite = false;
+    OrientationUKF::VelocityMeasurement bad = vz; bad.mu[1] = std::numeric_limits<double>::infinity();
+    try { g.integrateMeasurement(bad); } catch (const std::runtime_error&) { threw_nonfinite = true; }
+    OrientationState o; OrientationUKF::Covariance Po;
+    g.getCurrentState(o, Po);
+    double mo[14]; o.toArray(mo);
+    OrientationUKF::RotationRate::Mu rr = g.getRotationRate();
+    std::printf("\"threw_nonfinite\": %s, \"rotation_rate\": [%.17g, %.17g, %.17g], \"wgs84\": %.17g,\n", threw_nonfinite ? "true" : "false", rr[0], rr[1], rr[2],
+                GravitationalModel::WGS_84(0.92698121, 10.0));
+    print_state("orient", mo, 14, Po.data(), 13, true);
+    std::printf("}\n");
+    return 0;
+}

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of "
+                    "the N>1 plumbing on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
     ap.add_argument("--cpu-sample-seconds", type=float, default=10.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -114,18 +116,20 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     prec = spe.F64 if args.precision == "f64" else spe.F32
     tdtype = torch.float64 if prec == spe.F64 else torch.float32
-    per = args.filters // world
-    first = rank * per
-    if rank == world - 1:
-        per = args.filters - first
+    first, per = spe.shard_range(args.filters, world, rank)
 
     # ---- build the shard (host generation in chunks, then resident in HBM)
     eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
@@ -167,7 +171,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     status_or = eng.status_summary()
@@ -177,13 +181,14 @@ def main():
     if dist is not None:
         mu_ptr, _, _ = eng.device_views()
         mu_local = torch.as_tensor(_DevArray(mu_ptr, (per, 13), "<f8" if prec == spe.F64 else "<f4"), device=dev)
-        if per * world == args.filters:
-            out = torch.empty((args.filters, 13), dtype=tdtype, device=dev)
-            fence()
-            g0 = time.perf_counter()
-            dist.all_gather_into_tensor(out, mu_local)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - g0) * 1e3
+        if args.backend != "nccl":
+            mu_local = mu_local.cpu()
+        fence()
+        g0 = time.perf_counter()
+        gathered = spe.gather_means(mu_local, args.filters, world, dist)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert gathered.shape == (args.filters, 13)
 
     info = eng.last_launch_info()
     if rank == 0:

@@ -24,6 +24,9 @@
  *    Quaternion order (x,y,z,w) is Eigen's coefficient order.
  *  - "_dev" entry points take DEVICE pointers in the engine's compute precision (float or
  *    double) so that a caller whose inputs are already resident in HBM pays no PCIe copy.
+ *    They are consumed on the engine's stream: buffers produced on another stream must be
+ *    complete before the call (synchronise, or create the engine on the producer's stream),
+ *    and must stay valid until ukfb_sync() or a later synchronising call returns.
  *  - per-filter failures never abort a call: they are reported in the per-filter status word
  *    (UKFB_ST_*), and a failing filter keeps the state it had before the call (the reference
  *    throws before mutating: UnscentedKalmanFilter.hpp:110-124).

@@ -47,33 +47,20 @@ enum { QX = 0, QY = 1, QZ = 2, QW = 3 };
 // few ulp of T, far inside the 1e-9 (f64) / 1e-4 (f32) parity budget, and replace the ocml
 // sqrt / sincos / atan / IEEE-division expansions that dominated the first kernel's VALU time.
 // ---------------------------------------------------------------------------------------------
-// 1/sqrt(x): v_rsq + Goldschmidt refinement (two steps f64, one step f32).
+// 1/sqrt(x) and 1/x from the hardware seeds.  v_rsq_f64 / v_rcp_f64 deliver ~2^-26..2^-27 (llvm refines
+// them twice only to reach correct rounding), so ONE Newton step gives ~1e-15 relative, far inside the
+// 1e-9 budget; the f32 seeds are already 1 ulp and are used as they are (budget 1e-4).
 UKFB_DEV double fast_rsqrt(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    double y = x * r, h = 0.5 * r;
-    double e = fma(-h, y, 0.5);
-    y = fma(y, e, y);
-    h = fma(h, e, h);
-    e = fma(-h, y, 0.5);
-    h = fma(h, e, h);
-    return h + h;
+    const double r = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * r), r, 1.0);
+    return fma(0.5 * r, e, r);
 }
-UKFB_DEV float fast_rsqrt(float x) {
-    float r = __builtin_amdgcn_rsqf(x);
-    const float e = fmaf(-x * r, r, 1.0f);
-    return fmaf(0.5f * r, e, r);
-}
-// 1/x: v_rcp + Newton (two steps f64, one step f32).
+UKFB_DEV float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 UKFB_DEV double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
 }
-UKFB_DEV float fast_rcp(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(fmaf(-x, r, 1.0f), r, r);
-}
+UKFB_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 template <class T> struct Poly;
 template <> struct Poly<double> {

@@ -117,20 +117,27 @@ UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
 
 template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
     bool good = true;
+    // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
+    Lc[(l < D) ? l : dum] = (l >= 0) ? a[0] : T(0);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
-        Lc[(l < D) ? (k * LS + l) : dum] = (l >= k) ? a[k] : T(0);
         wsync();
         const T akk = Lc[k * LS + k];
         good = good && (akk > T(0));
         const T rs = fast_rsqrt(akk);
         const T t = a[k] * (rs * rs);
+        if (k + 1 < D) {
+            // software pipeline: finish column k+1 first and publish it, the rest of the trailing update
+            // overlaps the LDS round trip of that store
+            a[k + 1] = fma(-t, Lc[k * LS + k + 1], a[k + 1]);
+            Lc[(l < D) ? ((k + 1) * LS + l) : dum] = (l >= k + 1) ? a[k + 1] : T(0);
+        }
 #pragma unroll
-        for (int c = k + 1; c < D; ++c) a[c] = fma(-t, Lc[k * LS + c], a[c]);
+        for (int c = k + 2; c < D; ++c) a[c] = fma(-t, Lc[k * LS + c], a[c]);
         sfence();
     }
     ok = good;
+    wsync();
     const int lc = (l < D) ? l : (D - 1);
     return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l)
 }

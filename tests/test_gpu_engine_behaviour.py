@@ -104,6 +104,7 @@ def test_fused_cycle_with_gated_predict_and_masked_update(spe, oracle, onp):
     e = spe.BatchPoseUKF(n); e.initialize(mu, cov); e.set_acceleration(acc, acc_cov)
     zt = torch.from_numpy(zz).cuda(); Qt = torch.from_numpy(Q.reshape(n, 9)).cuda()
     mt = torch.from_numpy(models).cuda()
+    torch.cuda.synchronize()
     e.cycle_dev(0.01, 0, zt, Qt, meas_model_dev=mt)
     m, c, _ = e.state(); st = e.status()
     m_o, c_o, _ = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
@@ -207,6 +208,7 @@ def test_full_size_properties(spe, prec, n):
         full.initialize(mu, cov, first=lo)
         acc_t[lo:hi] = torch.from_numpy(acc).to(dev, tdt); z_t[lo:hi] = torch.from_numpy(z).to(dev, tdt)
         Q_t[lo:hi] = torch.from_numpy(Q.reshape(-1, 9)).to(dev, tdt)
+    torch.cuda.synchronize()   # device buffers are consumed on the engine's stream: make them ready first
     split = n // 2 + 3
     for eng, lo, hi in ((half_a, 0, split), (half_b, split, n)):
         for a in range(lo, hi, CH):
@@ -216,9 +218,11 @@ def test_full_size_properties(spe, prec, n):
     acc_cov = 0.01 * np.eye(3)
     for eng, lo, hi in ((full, 0, n), (half_a, 0, split), (half_b, split, n)):
         eng.set_acceleration(None, acc_cov)
-        eng.bind_acceleration_dev(acc_t[lo:hi].contiguous())
+        a_s, z_s, q_s = acc_t[lo:hi].contiguous(), z_t[lo:hi].contiguous(), Q_t[lo:hi].contiguous()
+        torch.cuda.synchronize()
+        eng.bind_acceleration_dev(a_s)
         for _ in range(3):
-            eng.cycle_dev(0.01, spe.MEAS_POS3, z_t[lo:hi].contiguous(), Q_t[lo:hi].contiguous())
+            eng.cycle_dev(0.01, spe.MEAS_POS3, z_s, q_s)
         assert eng.status_summary() == 0
     sel = np.concatenate([np.arange(0, 2048), np.arange(split - 1024, split + 1024), np.arange(n - 2048, n)])
     m_f, c_f, _ = full.state()
@@ -229,6 +233,7 @@ def test_full_size_properties(spe, prec, n):
     assert (np.linalg.eigvalsh(c_f[sel]) > 0).all()
     # uninformative measurement: identity up to rounding
     big = torch.eye(3, dtype=tdt, device=dev).reshape(1, 9).repeat(n, 1) * 1e12
+    torch.cuda.synchronize()
     full.update_dev(spe.MEAS_POS3, z_t, big)
     m_i, c_i, _ = full.state()
     tol = 1e-8 if prec == 0 else 1e-4

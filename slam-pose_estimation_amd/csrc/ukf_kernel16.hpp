@@ -73,14 +73,37 @@ template <class T> struct MT<PoseM<T>> {
     static constexpr unsigned long long SEL2 = nib(0, 2) | nib(1, 15) | nib(2, 15) | nib(3, 15) | nib(4, 9) | nib(5, 15) |
                                                nib(6, 15) | nib(7, 15) | nib(8, 12);
     static constexpr bool HAS_EUCLID_MEAS = true;
-    // orientation-dependent measurement (model id 3): the quaternion itself
-    UKFB_DEV static void gen_measure(const T (&x)[13], T (&z)[4]) { z[0] = x[3]; z[1] = x[4]; z[2] = x[5]; z[3] = x[6]; }
+    // orientation-dependent measurement (model id 3, PoseUKF.cpp:28-33): the quaternion itself.
+    // qp / qm / q0: orientation of the +column, -column and centre sigma point.
+    UKFB_DEV static void gen_measure(const T (&qp)[4], const T (&qm)[4], const T (&q0)[4], const T*, const T*, T,
+                                     T (&zp)[4], T (&zm)[4], T (&z0)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { zp[k] = qp[k]; zm[k] = qm[k]; z0[k] = q0[k]; }
+    }
 };
 template <class T> struct MT<OrientM<T>> {
     static constexpr int Q = 0, RT = 0, TR = 3, TC = 3;
     static constexpr unsigned long long SEL0 = 0, SEL1 = 0, SEL2 = 0;
     static constexpr bool HAS_EUCLID_MEAS = false;
-    UKFB_DEV static void gen_measure(const T (&x)[14], T (&z)[4]) { OrientM<T>::measure(x, 9, z); }
+    // velocityMeasurementModel (OrientationUKF.cpp:34-39): q.inverse() * v for the three sigma points;
+    // the velocity (stored 4..6, tangent 3..5) comes straight from the mean staging and the factor column
+    UKFB_DEV static void body_vel(const T (&q)[4], const T (&v)[3], T (&z)[4]) {
+        const T rn = fast_rcp(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const T qi[4] = {-q[0] * rn, -q[1] * rn, -q[2] * rn, q[3] * rn};
+        T r[3];
+        quat_rotate(qi, v, r);
+        z[0] = r[0]; z[1] = r[1]; z[2] = r[2]; z[3] = T(0);
+    }
+    UKFB_DEV static void gen_measure(const T (&qp)[4], const T (&qm)[4], const T (&q0)[4], const T* MUS, const T* colp,
+                                     T w, T (&zp)[4], T (&zm)[4], T (&z0)[4]) {
+        const T v0[3] = {MUS[4], MUS[5], MUS[6]};
+        const T cv[3] = {colp[3] * w, colp[4] * w, colp[5] * w};
+        const T vp[3] = {v0[0] + cv[0], v0[1] + cv[1], v0[2] + cv[2]};
+        const T vm[3] = {v0[0] - cv[0], v0[1] - cv[1], v0[2] - cv[2]};
+        body_vel(qp, vp, zp);
+        body_vel(qm, vm, zm);
+        body_vel(q0, v0, z0);
+    }
 };
 
 template <class T, class M> struct Layout16 {
@@ -588,17 +611,13 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 ZQ[(l < 12) ? l : (LY::DUM - LY::ZQ)] = (l < 3) ? zv : qv;
             }
             wsync();
-            T zin[3], Qm[9];
+            T zin[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) zin[k] = ZQ[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Qm[k] = ZQ[3 + k];
             if (M::CHECK_MEAS_FINITE) {
                 bool fin = true;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) fin = fin && m_finite(zin[k]);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) fin = fin && m_finite(Qm[k]);
+                for (int k = 0; k < 12; ++k) fin = fin && m_finite(ZQ[k]);
                 st |= (do_u && !fin) ? ST_ERR_NONFINITE_MEAS : 0u;
                 do_u = do_u && fin;
             }
@@ -606,13 +625,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             const int m = M::meas_dim(midc);
             const bool so3 = M::meas_is_so3(midc);
             const bool need_q = so3 || (M::MODEL == 1);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const T pad = (r == c) ? T(1) : T(0);
-                    Qm[r * 3 + c] = (r >= m || c >= m) ? pad : Qm[r * 3 + c];
-                }
             T zval[4];
             {
                 T qe[4];
@@ -621,140 +633,177 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 for (int k = 0; k < 3; ++k) zval[k] = so3 ? qe[k] : ((k < m) ? zin[k] : T(0));
                 zval[3] = so3 ? qe[3] : T(0);
             }
-            bool ok1;
-            T rs;
-            T zp[4] = {T(0), T(0), T(0), T(0)}, zm[4] = {T(0), T(0), T(0), T(0)}, z0[4] = {T(0), T(0), T(0), T(0)};
-            {
-                T arow[D];
-                load_row<T, D>(PKS, l, arow);
-                rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, ok1);
-                wsync();
-            }
+            // Measurement statistics: S (innovation covariance), cx (row l of Sigma_xz), innovation.
+            bool ok1 = true, zconv = true;
+            T Sm[9], cx[3], innov[3];
+            T* wrow = has_pair ? (WK + l * 4) : DUMP;
+            const int la = has_pair ? l : (D - 1);
             if (MT<M>::HAS_EUCLID_MEAS) {
-                // sub-state selections (PoseUKF.cpp:7-26,35-69): Z = mu[sel] +- L[sel][l], read by index from LDS
-                const int lc = has_pair ? l : (D - 1);
-                const T w = has_pair ? rs : T(0);
+                // Sub-state selections (PoseUKF.cpp:7-26,35-69) are LINEAR in the tangent, and the unscented
+                // transform of a linear map is exact: with Sigma = L L^T the sigma-point sums collapse to
+                //   zbar = mu[sel],  S = Sigma[sel][sel] + Q,  Sigma_xz = Sigma[:, sel]
+                // (the same identity applyDelta uses), so neither the factorisation nor the spread is needed.
                 const unsigned long long sel[3] = {MT<M>::SEL0, MT<M>::SEL1, MT<M>::SEL2};
+                int ti[3];
+                bool used[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int sk = int((sel[k] >> (4 * midc)) & 15ull);
-                    const bool used = sk != 15;
-                    const int si = used ? sk : 0;
-                    const int ti = (si < Q) ? si : (si - 1);
-                    const T m0 = used ? MUS[si] : T(0);
-                    const T cv = used ? Lc[lc * LS + ti] * w : T(0);
-                    zp[k] = m0 + cv; zm[k] = m0 - cv; z0[k] = m0;
+                    used[k] = sk != 15;
+                    const int si = used[k] ? sk : 0;
+                    ti[k] = (si < Q) ? si : (si - 1);
+                    const T m0 = MUS[si];
+                    innov[k] = used[k] ? (zin[k] - m0) : T(0);
+                    const int hi = la > ti[k] ? la : ti[k], lo = la > ti[k] ? ti[k] : la;
+                    const T sx = PKS[hi * (hi + 1) / 2 + lo];
+                    cx[k] = used[k] ? sx : T(0);
                 }
-            }
-            if (__any(need_q)) {   // wave-uniform: measurement models that read the orientation
-                T mu_r[S], col[D], xp[S], xm[S], gp[4], gm[4], g0[4];
-#pragma unroll
-                for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
-                load_column<T, D, LS>(Lc, l, rs, col);
-                sigma_pair<T, M>(mu_r, col, true, xp, xm);
-                MT<M>::gen_measure(xp, gp);
-                MT<M>::gen_measure(xm, gm);
-                MT<M>::gen_measure(mu_r, g0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    zp[k] = need_q ? gp[k] : zp[k];
-                    zm[k] = need_q ? gm[k] : zm[k];
-                    z0[k] = need_q ? g0[k] : z0[k];
-                }
-            }
-            sfence();
-            // ---- mean of Z.  Euclidean: one pass is exact.  SO(3): iterate on the manifold.
-            T zref[4] = {z0[0], z0[1], z0[2], z0[3]};
-            bool zconv = true;
-            if (__any(so3 && do_u)) {
-                bool active = so3;
-                int it = 0;
-                while (__any(active)) {
-                    T rp[3], rm[3], r0v[3], mr[3];
-                    rot_minus(zp, zref, rp);
-                    rot_minus(zm, zref, rm);
-                    rot_minus(z0, zref, r0v);
-                    T m2 = T(0);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const T loc = has_pair ? (rp[k] + rm[k]) : T(0);
-                        mr[k] = (row_allreduce(loc) + r0v[k]) * (T(1) / T(N));
-                        m2 += mr[k] * mr[k];
-                    }
-                    T e[4], nq[4];
-                    so3_exp_fast(mr, T(1), e);
-                    quat_mul(zref, e, nq);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) zref[k] = active ? nq[k] : zref[k];
-                    const bool more = m2 > a.mean_tol * a.mean_tol;
-                    const bool capped = more && (it + 1 >= a.mean_max_it);
-                    it += (active && more) ? 1 : 0;
-                    zconv = zconv && !(active && capped);
-                    active = active && more && !capped;
-                }
-            }
-            {
-                T zr[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T loc = has_pair ? ((zp[k] - z0[k]) + (zm[k] - z0[k])) : T(0);
-                    zr[k] = z0[k] + row_allreduce(loc) * (T(1) / T(N));
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) zref[k] = so3 ? zref[k] : zr[k];
-            }
-            sfence();
-            // ---- deltas to the measurement mean, S, innovation
-            T dzp[3], dzm[3], dz0[3], innov[3];
-            {
-                T a3[3] = {T(0), T(0), T(0)}, b3[3] = {T(0), T(0), T(0)}, c3[3] = {T(0), T(0), T(0)},
-                  d3[3] = {T(0), T(0), T(0)};
-                if (__any(so3)) {
-                    rot_minus(zp, zref, a3);
-                    rot_minus(zm, zref, b3);
-                    rot_minus(z0, zref, c3);
-                    rot_minus(zval, zref, d3);
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    dzp[k] = so3 ? a3[k] : (zp[k] - zref[k]);
-                    dzm[k] = so3 ? b3[k] : (zm[k] - zref[k]);
-                    dz0[k] = so3 ? c3[k] : (z0[k] - zref[k]);
-                    innov[k] = so3 ? d3[k] : (zval[k] - zref[k]);
-                }
-            }
-            T Sm[9];
-            {
-                T u6[6];
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) {
-                        const T loc = has_pair ? fma(dzp[r], dzp[c], dzm[r] * dzm[c]) : T(0);
-                        u6[r * (r + 1) / 2 + c] = T(0.5) * (row_allreduce(loc) + dz0[r] * dz0[c]);
+                    for (int c = 0; c < 3; ++c) {
+                        const int hi = ti[r] > ti[c] ? ti[r] : ti[c], lo = ti[r] > ti[c] ? ti[c] : ti[r];
+                        const T pad = (r == c) ? T(1) : T(0);
+                        const T sv = PKS[hi * (hi + 1) / 2 + lo] + ZQ[3 + r * 3 + c];
+                        Sm[r * 3 + c] = (used[r] && used[c]) ? sv : pad;
                     }
-                Sm[0] = u6[0] + Qm[0];
-                Sm[3] = u6[1] + Qm[3]; Sm[1] = u6[1] + Qm[1];
-                Sm[4] = u6[2] + Qm[4];
-                Sm[6] = u6[3] + Qm[6]; Sm[2] = u6[3] + Qm[2];
-                Sm[7] = u6[4] + Qm[7]; Sm[5] = u6[4] + Qm[5];
-                Sm[8] = u6[5] + Qm[8];
+            }
+            if (__any(need_q)) {
+                // Orientation-dependent models (PoseUKF.cpp:28-33, OrientationUKF.cpp:34-39): full sigma-point
+                // path of ukfom::update.  Wave-uniform branch; results are selected per filter below.
+                bool okg;
+                T rs;
+                {
+                    T arow[D];
+                    load_row<T, D>(PKS, l, arow);
+                    rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, okg);
+                    wsync();
+                }
+                T zp[4], zm[4], z0[4];
+                {
+                    const T w = has_pair ? rs : T(0);
+                    const T* colp = Lc + la * LS;
+                    const T q0[4] = {MUS[Q], MUS[Q + 1], MUS[Q + 2], MUS[Q + 3]};
+                    const T cr[3] = {colp[RT] * w, colp[RT + 1] * w, colp[RT + 2] * w};
+                    T e[4], qp[4], qm[4];
+                    so3_exp_fast(cr, T(1), e);
+                    const T ec[4] = {-e[0], -e[1], -e[2], e[3]};
+                    quat_mul(q0, e, qp);
+                    quat_mul(q0, ec, qm);
+                    MT<M>::gen_measure(qp, qm, q0, MUS, colp, w, zp, zm, z0);
+                }
+                sfence();
+                // ---- mean of Z.  Euclidean: one pass is exact.  SO(3): iterate on the manifold.
+                T zref[4] = {z0[0], z0[1], z0[2], z0[3]};
+                bool zc = true;
+                if (__any(so3 && do_u)) {
+                    bool active = so3;
+                    int it = 0;
+                    while (__any(active)) {
+                        T rp[3], rm[3], r0v[3], mr[3];
+                        rot_minus(zp, zref, rp);
+                        rot_minus(zm, zref, rm);
+                        rot_minus(z0, zref, r0v);
+                        T m2 = T(0);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const T loc = has_pair ? (rp[k] + rm[k]) : T(0);
+                            mr[k] = (row_allreduce(loc) + r0v[k]) * (T(1) / T(N));
+                            m2 += mr[k] * mr[k];
+                        }
+                        T e[4], nq[4];
+                        so3_exp_fast(mr, T(1), e);
+                        quat_mul(zref, e, nq);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) zref[k] = active ? nq[k] : zref[k];
+                        const bool more = m2 > a.mean_tol * a.mean_tol;
+                        const bool capped = more && (it + 1 >= a.mean_max_it);
+                        it += (active && more) ? 1 : 0;
+                        zc = zc && !(active && capped);
+                        active = active && more && !capped;
+                    }
+                }
+                {
+                    T zr[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T loc = has_pair ? ((zp[k] - z0[k]) + (zm[k] - z0[k])) : T(0);
+                        zr[k] = z0[k] + row_allreduce(loc) * (T(1) / T(N));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) zref[k] = so3 ? zref[k] : zr[k];
+                }
+                sfence();
+                // ---- deltas to the measurement mean, S, innovation
+                T dzp[3], dzm[3], dz0[3], inn[3];
+                {
+                    T a3[3] = {T(0), T(0), T(0)}, b3[3] = {T(0), T(0), T(0)}, c3[3] = {T(0), T(0), T(0)},
+                      d3[3] = {T(0), T(0), T(0)};
+                    if (__any(so3)) {
+                        rot_minus(zp, zref, a3);
+                        rot_minus(zm, zref, b3);
+                        rot_minus(z0, zref, c3);
+                        rot_minus(zval, zref, d3);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dzp[k] = so3 ? a3[k] : (zp[k] - zref[k]);
+                        dzm[k] = so3 ? b3[k] : (zm[k] - zref[k]);
+                        dz0[k] = so3 ? c3[k] : (z0[k] - zref[k]);
+                        inn[k] = so3 ? d3[k] : (zval[k] - zref[k]);
+                    }
+                }
+                T Sg[9];
+                {
+                    // measurement covariance from its LDS staging; unused trailing dimensions are decoupled
+                    // (Q = I there, z = h = 0), which leaves the leading m x m inverse bit-equal
+                    T Qm[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const T pad = (r == c) ? T(1) : T(0);
+                            Qm[r * 3 + c] = (r >= m || c >= m) ? pad : ZQ[3 + r * 3 + c];
+                        }
+                    T u6[6];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) {
+                            const T loc = has_pair ? fma(dzp[r], dzp[c], dzm[r] * dzm[c]) : T(0);
+                            u6[r * (r + 1) / 2 + c] = T(0.5) * (row_allreduce(loc) + dz0[r] * dz0[c]);
+                        }
+                    Sg[0] = u6[0] + Qm[0];
+                    Sg[3] = u6[1] + Qm[3]; Sg[1] = u6[1] + Qm[1];
+                    Sg[4] = u6[2] + Qm[4];
+                    Sg[6] = u6[3] + Qm[6]; Sg[2] = u6[3] + Qm[2];
+                    Sg[7] = u6[4] + Qm[7]; Sg[5] = u6[4] + Qm[5];
+                    Sg[8] = u6[5] + Qm[8];
+                }
+                sfence();
+                // ---- cross covariance: Cxz[a][c] = sum_l L[a][l] * 0.5 (dz+_l - dz-_l)[c]
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wrow[k] = T(0.5) * rs * (dzp[k] - dzm[k]);
+                wsync();
+                T cg[3] = {T(0), T(0), T(0)};
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const T v = Lc[j * LS + la];   // zero for j > la
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) cg[k] = fma(v, WK[j * 4 + k], cg[k]);
+                    if ((j & 3) == 3) sfence();
+                }
+                ok1 = need_q ? okg : ok1;
+                zconv = need_q ? zc : zconv;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Sm[k] = (need_q || !MT<M>::HAS_EUCLID_MEAS) ? Sg[k] : Sm[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    cx[k] = (need_q || !MT<M>::HAS_EUCLID_MEAS) ? cg[k] : cx[k];
+                    innov[k] = (need_q || !MT<M>::HAS_EUCLID_MEAS) ? inn[k] : innov[k];
+                }
             }
             sfence();
-            // ---- cross covariance: Cxz[a][c] = sum_l L[a][l] * 0.5 (dz+_l - dz-_l)[c]
-            T* wrow = has_pair ? (WK + l * 4) : DUMP;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wrow[k] = T(0.5) * rs * (dzp[k] - dzm[k]);
-            wsync();
-            const int la = has_pair ? l : (D - 1);
-            T cx[3] = {T(0), T(0), T(0)};
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const T v = Lc[j * LS + la];   // zero for j > la
-#pragma unroll
-                for (int k = 0; k < 3; ++k) cx[k] = fma(v, WK[j * 4 + k], cx[k]);
-                if ((j & 3) == 3) sfence();
-            }
             T Kr[3], KSr[3];
             bool accept;
             {

@@ -147,8 +147,7 @@ template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int
         wsync();
         const T akk = Lc[k * LS + k];
         good = good && (akk > T(0));
-        const T rs = fast_rsqrt(akk);
-        const T t = a[k] * (rs * rs);
+        const T t = a[k] * fast_rcp(akk);   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
         if (k + 1 < D) {
             // software pipeline: finish column k+1 first and publish it, the rest of the trailing update
             // overlaps the LDS round trip of that store
@@ -409,14 +408,18 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             const bool pc = do_p && ok;            // this filter's predict will be committed
             sfence();
-            process_fast((M*)nullptr, ref, pin);   // centre point, carried by every lane
-            sfence();
-            process_fast((M*)nullptr, xp, pin);
+            process_fast((M*)nullptr, xp, pin);    // lanes >= D carry the centre point (their column is zero)
             sfence();
             process_fast((M*)nullptr, xm, pin);
             sfence();
+            {   // propagated centre point: lane D publishes it, every lane starts the mean from it
+                T* dst = has_ctr ? WK : DUMP;
 #pragma unroll
-            for (int s = 0; s < S; ++s) xp[s] = has_ctr ? ref[s] : xp[s];
+                for (int s = 0; s < S; ++s) dst[s] = xp[s];
+                wsync();
+#pragma unroll
+                for (int s = 0; s < S; ++s) ref[s] = WK[s];
+            }
             const bool has_p = has_pair || has_ctr, has_m = has_pair;
             const T wp = has_p ? T(1) : T(0), wm = has_m ? T(1) : T(0);
 

@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 TOTAL_FILTERS = 1_048_576
 DT = 0.01
 ALG_SCALARS_POSE = 2 * 157 + 15  # read+write (13 + 144) + acc 3 + z 3 + Q 9
+ALG_SCALARS_ORIENT = 2 * 183 + 18  # read+write (14 + 169) + gyro 3 + acc 3 + z 3 + Q 9
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -50,6 +51,9 @@ def parse():
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["pose", "pose-mixed", "orient"], default="pose",
+                    help="pose: the headline metric (default). pose-mixed: BASELINE config 5 (per-filter model id over "
+                         "the 9 Pose models, 25 %% inactive). orient: config 4 (OrientationState predict + body-velocity update)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of "
                     "the N>1 plumbing on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
@@ -132,28 +136,55 @@ def main():
     first, per = spe.shard_range(args.filters, world, rank)
 
     # ---- build the shard (host generation in chunks, then resident in HBM)
-    eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
     CH = 131072
     n_ring = 4
+    orient = args.workload == "orient"
+    S = 14 if orient else 13
+    if orient:
+        sy = spe.synth
+        eng = spe.BatchOrientationUKF(per, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec,
+                                      device=dev.index, lanes_per_filter=args.lanes_per_filter)
+        eng.set_process_noise(sy.orient_process_noise())
+    else:
+        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
     acc_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)]
+    gyr_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)] if orient else None
     z_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)]
     Q_d = [torch.empty((per, 9), dtype=tdtype, device=dev) for _ in range(n_ring)]
+    m_d = [torch.empty((per,), dtype=torch.int32, device=dev) for _ in range(n_ring)] if args.workload == "pose-mixed" else None
     for lo in range(0, per, CH):
         hi = min(per, lo + CH)
-        mu, cov = spe.synth.pose_initial(hi - lo, first=first + lo)
+        if orient:
+            mu, cov = spe.synth.orient_initial(hi - lo, first=first + lo)
+        else:
+            mu, cov = spe.synth.pose_initial(hi - lo, first=first + lo)
         eng.initialize(mu, cov, first=lo)
         for k in range(n_ring):
-            acc, z, Q = spe.synth.pose_cycle_inputs(hi - lo, k, mu[:, :3], first=first + lo)
+            if orient:
+                gyro, acc, z, Q = spe.synth.orient_cycle_inputs(hi - lo, k, mu[:, :4], first=first + lo)
+                gyr_d[k][lo:hi] = torch.from_numpy(gyro).to(dev, tdtype)
+            else:
+                acc, z, Q = spe.synth.pose_cycle_inputs(hi - lo, k, mu[:, :3], first=first + lo,
+                                                        random_q=args.workload == "pose-mixed")
+                if args.workload == "pose-mixed":
+                    models = spe.synth.pose_mixed_models(hi - lo, k, first=first + lo)
+                    z = spe.synth.pose_measurement_for_model(mu, models, z - mu[:, :3])
+                    m_d[k][lo:hi] = torch.from_numpy(models).to(dev)
             acc_d[k][lo:hi] = torch.from_numpy(acc).to(dev, tdtype)
             z_d[k][lo:hi] = torch.from_numpy(z).to(dev, tdtype)
             Q_d[k][lo:hi] = torch.from_numpy(Q.reshape(-1, 9)).to(dev, tdtype)
-    eng.set_acceleration(None, 0.01 * np.eye(3))
+    if not orient:
+        eng.set_acceleration(None, 0.01 * np.eye(3))
     torch.cuda.synchronize()
 
     def step(k):
         r = k % n_ring
-        eng.bind_acceleration_dev(acc_d[r])
-        eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r])
+        if orient:
+            eng.bind_orient_inputs_dev(gyr_d[r], acc_d[r])
+            eng.cycle_dev(DT, spe.MEAS_ORIENT_BODYVEL3, z_d[r], Q_d[r])
+        else:
+            eng.bind_acceleration_dev(acc_d[r])
+            eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r], meas_model_dev=m_d[r] if m_d else None)
 
     def fence():
         if dist is not None:
@@ -180,7 +211,7 @@ def main():
     gather_ms = None
     if dist is not None:
         mu_ptr, _, _ = eng.device_views()
-        mu_local = torch.as_tensor(_DevArray(mu_ptr, (per, 13), "<f8" if prec == spe.F64 else "<f4"), device=dev)
+        mu_local = torch.as_tensor(_DevArray(mu_ptr, (per, S), "<f8" if prec == spe.F64 else "<f4"), device=dev)
         if args.backend != "nccl":
             mu_local = mu_local.cpu()
         fence()
@@ -188,17 +219,17 @@ def main():
         gathered = spe.gather_means(mu_local, args.filters, world, dist)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        assert gathered.shape == (args.filters, 13)
+        assert gathered.shape == (args.filters, S)
 
     info = eng.last_launch_info()
     if rank == 0:
         tsize = 8 if prec == spe.F64 else 4
         value = args.filters * args.steps / elapsed
-        alg_bytes_launch = ALG_SCALARS_POSE * tsize * per
+        alg_bytes_launch = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * tsize * per
         kernel_ms = kernel_ms_total / args.steps
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "UKF predict+update filter-cycles/s, PoseWithVelocity filters",
+            "metric": "UKF predict+update filter-cycles/s, " + ("OrientationState" if orient else "PoseWithVelocity") + " filters",
             "value": value,
             "unit": "filter-cycles/s",
             "n_gpus": world,
@@ -210,9 +241,12 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": f"{args.filters} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)"
-                                   f"+PositionMeasurement update per step, {args.precision}, "
-                                   f"{per} filters per GPU", "filters": args.filters, "filters_per_gpu": per,
+            "config": {"workload": (f"{args.filters} OrientationState UKF filters, fused predict(gyro+acc, dt=0.01)"
+                                    f"+body-velocity update per step, {args.precision}, {per} filters per GPU" if orient else
+                                    f"{args.filters} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)+"
+                                    + ("per-filter measurement model (9 models, 25 % inactive)" if args.workload == "pose-mixed"
+                                       else "PositionMeasurement") + f" update per step, {args.precision}, {per} filters per GPU"),
+                       "filters": args.filters, "filters_per_gpu": per,
                        "lanes_per_filter": 64 // max(1, info["filters_per_workgroup"]),
                        "parallelism": f"filter-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,7 +258,7 @@ def main():
             "status_or": status_or,
             "gather_ms": gather_ms,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "pose":
             out["cpu_baseline"] = cpu_baseline(args)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None

@@ -120,7 +120,10 @@ template <class T, class M> struct Layout16 {
     static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
     static constexpr int WK = MISC + 40;                    // D*4 (<= 56): W / K / cross-term exchange
     static constexpr int DUM = MISC + 96;                   // 16 : sink for lane-predicated stores
-    static constexpr int PF = MISC + 112;
+    static constexpr int PF_RAW = MISC + 112;
+    // the four slices of a wavefront must not start on the same LDS bank (measured: a slice stride that is
+    // a multiple of 32 dwords costs 25-50 %: every broadcast read becomes a 4-way conflict)
+    static constexpr int PF = PF_RAW + (((PF_RAW * int(sizeof(T)) / 4) % 32 == 0) ? 2 * VEC : 0);
     static_assert(D * LS + PKP <= N * LS, "packed staging must fit behind the factor");
     static_assert(D * 4 <= 56 && PF % VEC == 0 && LS <= 16 && S <= 16, "scratch layout");
 };

@@ -159,6 +159,19 @@ int ukfb_orient_bind_inputs_dev(ukfb_engine* e, const void* gyro_dev, const void
 /* OrientationUKF::getRotationRate (:74-77) for filters [first, first+count): out [count][3] */
 int ukfb_orient_get_rotation_rate(ukfb_engine* e, int64_t first, int64_t count, double* out);
 
+/* ---- BodyStateMeasurement adapters (pose_with_velocity/BodyStateMeasurement.hpp:14-39) ---- */
+/* One record per filter, 49 doubles: position(3) orientation(x,y,z,w) velocity(3) angular_velocity(3)
+ * cov_position(9) cov_orientation(9) cov_velocity(9) cov_angular_velocity(9) (3x3 blocks, row-major) --
+ * the fields of base::samples::RigidBodyState that the reference converts.
+ * export = toRigidBodyState (:28-39): velocity is rotated into the navigation frame,
+ *          velocity_out = orientation * velocity (:32); the blocks are the diagonal 3x3 blocks (:35-38).
+ * import = fromRigidBodyState (:14-26) followed by initializeFilter: fields copied as they are (no inverse
+ *          rotation, as in the reference), covariance = the four blocks at (0,0) (3,3) (6,6) (9,9), zero
+ *          elsewhere (:21-25).  Pose engines only. */
+#define UKFB_BODY_STATE_SCALARS 49
+int ukfb_pose_export_body_states(ukfb_engine* e, int64_t first, int64_t count, double* out);
+int ukfb_pose_import_body_states(ukfb_engine* e, int64_t first, int64_t count, const double* in);
+
 /* ---- predict (UnscentedKalmanFilter.hpp:83-125 + predictionStepImpl) --------------------- */
 /* predictionStep(delta_t) with one dt for every filter */
 int ukfb_predict(ukfb_engine* e, double dt);

@@ -425,3 +425,26 @@ def orient_update(mu, sigma, z, Q3, **kw):
 def orient_rotation_rate(mu, omega, earth):
     """getRotationRate (OrientationUKF.cpp:74-77)."""
     return omega - mu[:, 7:10] - quat_rotate(quat_inverse(mu[:, 0:4]), earth)
+
+
+# --------------------------------------------------------------------------- BodyStateMeasurement
+def body_state_export(mu, cov):
+    """toRigidBodyState (BodyStateMeasurement.hpp:28-39) -> [B, 49] records (layout: include/ukf_batch.h)."""
+    B = mu.shape[0]
+    out = np.empty((B, 49))
+    out[:, 0:7] = mu[:, 0:7]
+    out[:, 7:10] = quat_rotate(mu[:, 3:7], mu[:, 7:10])     # velocity = orientation * velocity (:32)
+    out[:, 10:13] = mu[:, 10:13]
+    for b in range(4):
+        out[:, 13 + 9 * b:22 + 9 * b] = cov[:, 3 * b:3 * b + 3, 3 * b:3 * b + 3].reshape(B, 9)
+    return out
+
+
+def body_state_import(rec):
+    """fromRigidBodyState (BodyStateMeasurement.hpp:14-26) -> (mu [B,13], cov [B,12,12])."""
+    B = rec.shape[0]
+    mu = rec[:, 0:13].copy()
+    cov = np.zeros((B, 12, 12))
+    for b in range(4):
+        cov[:, 3 * b:3 * b + 3, 3 * b:3 * b + 3] = rec[:, 13 + 9 * b:22 + 9 * b].reshape(B, 3, 3)
+    return mu, cov

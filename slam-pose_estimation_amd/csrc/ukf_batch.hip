@@ -154,6 +154,80 @@ int rebuild_racc(ukfb_engine* e) {
     return UKFB_OK;
 }
 
+// BodyStateMeasurement::toRigidBodyState for a batch: one thread per output scalar (coalesced stores).
+template <class T> __global__ void export_body_states_kernel(const T* mu, const T* cov, int64_t first, int64_t count, T* out) {
+    const int64_t gid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (gid >= count * 49) return;
+    const int64_t i = gid / 49, f = first + i;
+    const int j = int(gid % 49);
+    const T* m = mu + f * 13;
+    T v;
+    if (j < 7) {
+        v = m[j];                                   // position, orientation
+    } else if (j < 10) {                            // velocity rotated into the navigation frame (:32)
+        const T qx = m[3], qy = m[4], qz = m[5], qw = m[6];
+        const T vx = m[7], vy = m[8], vz = m[9];
+        T ux = qy * vz - qz * vy, uy = qz * vx - qx * vz, uz = qx * vy - qy * vx;
+        ux += ux; uy += uy; uz += uz;
+        const T r0 = vx + qw * ux + (qy * uz - qz * uy);
+        const T r1 = vy + qw * uy + (qz * ux - qx * uz);
+        const T r2 = vz + qw * uz + (qx * uy - qy * ux);
+        v = (j == 7) ? r0 : ((j == 8) ? r1 : r2);
+    } else if (j < 13) {
+        v = m[j];                                   // angular velocity
+    } else {
+        const int b = (j - 13) / 9, rc = (j - 13) % 9, r = 3 * b + rc / 3, c = 3 * b + rc % 3;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        v = cov[f * 78 + hi * (hi + 1) / 2 + lo];
+    }
+    out[gid] = v;
+}
+// fromRigidBodyState + initializeFilter: one thread per stored scalar (13 mean + 78 packed covariance)
+template <class T> __global__ void import_body_states_kernel(const T* in, int64_t first, int64_t count, T* mu, T* cov) {
+    const int64_t gid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (gid >= count * 91) return;
+    const int64_t i = gid / 91, f = first + i;
+    const int j = int(gid % 91);
+    const T* rec = in + i * 49;
+    if (j < 13) {
+        mu[f * 13 + j] = rec[j];
+    } else {
+        const int e = j - 13;
+        int r = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
+        if (r * (r + 1) / 2 > e) --r;
+        if ((r + 1) * (r + 2) / 2 <= e) ++r;
+        const int c = e - r * (r + 1) / 2;
+        const bool same = (r / 3) == (c / 3);
+        const T v = same ? rec[13 + (r / 3) * 9 + (r % 3) * 3 + (c % 3)] : T(0);
+        cov[f * 78 + e] = v;
+    }
+}
+
+template <class T> int export_body_states(ukfb_engine* e, int64_t first, int64_t count, double* out) {
+    T* dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), size_t(count) * 49 * sizeof(T)));
+    const int blocks = int((count * 49 + 255) / 256);
+    hipLaunchKernelGGL(export_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(e->mu),
+                       static_cast<const T*>(e->cov), first, count, dev);
+    int rc = download(e, dev, 0, out, size_t(count) * 49);
+    HIP_TRY(hipFree(dev));
+    return rc;
+}
+template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t count, const double* in) {
+    T* dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), size_t(count) * 49 * sizeof(T)));
+    int rc = upload(e, dev, 0, in, size_t(count) * 49);
+    if (rc) return rc;
+    const int blocks = int((count * 91 + 255) / 256);
+    hipLaunchKernelGGL(import_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(dev), first,
+                       count, static_cast<T*>(e->mu), static_cast<T*>(e->cov));
+    HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
+    HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(dev));
+    return UKFB_OK;
+}
+
 __global__ void or_reduce_kernel(const uint32_t* st, int64_t n, uint32_t* out) {
     uint32_t v = 0;
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
@@ -530,6 +604,25 @@ int ukfb_orient_get_rotation_rate(ukfb_engine* e, int64_t first, int64_t count, 
         out[i * 3 + 2] = w[size_t(i) * 3 + 2] - m[9] - r2;
     }
     return UKFB_OK;
+}
+
+// ---- BodyStateMeasurement adapters ----------------------------------------------------------------
+int ukfb_pose_export_body_states(ukfb_engine* e, int64_t first, int64_t count, double* out) {
+    if (!e || !out) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
+    if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    if (count == 0) return UKFB_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    return e->prec == UKFB_F64 ? export_body_states<double>(e, first, count, out) : export_body_states<float>(e, first, count, out);
+}
+
+int ukfb_pose_import_body_states(ukfb_engine* e, int64_t first, int64_t count, const double* in) {
+    if (!e || !in) return UKFB_ERR_INVALID_ARG;
+    if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
+    if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
+    if (count == 0) return UKFB_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    return e->prec == UKFB_F64 ? import_body_states<double>(e, first, count, in) : import_body_states<float>(e, first, count, in);
 }
 
 // ---- predict ------------------------------------------------------------------------------------

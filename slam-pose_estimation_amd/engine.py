@@ -43,8 +43,9 @@ EXPORTS = [
     "ukfb_orient_set_inputs", "ukfb_orient_bind_inputs_dev", "ukfb_orient_get_rotation_rate", "ukfb_predict",
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
     "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_last_launch_info",
-    "ukfb_timer_begin", "ukfb_timer_end",
+    "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
 ]
+BODY_STATE_SCALARS = 49
 
 
 class Config(C.Structure):
@@ -207,6 +208,20 @@ class BatchUKF:
         n = am.shape[0] if am is not None else 0
         _chk(self._lib.ukfb_pose_set_acceleration(self._h, C.c_int64(first), C.c_int64(n), _pd(am), _pd(ac)),
              "ukfb_pose_set_acceleration")
+
+    def export_body_states(self, first: int = 0, count: Optional[int] = None):
+        """BodyStateMeasurement::toRigidBodyState for a range of filters -> [count, 49] records."""
+        count = self.capacity - first if count is None else count
+        out = np.empty((count, BODY_STATE_SCALARS))
+        _chk(self._lib.ukfb_pose_export_body_states(self._h, C.c_int64(first), C.c_int64(count), _pd(out)),
+             "ukfb_pose_export_body_states")
+        return out
+
+    def import_body_states(self, records, first: int = 0):
+        """BodyStateMeasurement::fromRigidBodyState + initializeFilter from [count, 49] records."""
+        rec = _f64(records, (-1, BODY_STATE_SCALARS))
+        _chk(self._lib.ukfb_pose_import_body_states(self._h, C.c_int64(first), C.c_int64(rec.shape[0]), _pd(rec)),
+             "ukfb_pose_import_body_states")
 
     def bind_acceleration_dev(self, acc_dev):
         _chk(self._lib.ukfb_pose_bind_acceleration_dev(self._h, _devptr(acc_dev)), "ukfb_pose_bind_acceleration_dev")

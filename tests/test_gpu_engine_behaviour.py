@@ -238,3 +238,27 @@ def test_full_size_properties(spe, prec, n):
     m_i, c_i, _ = full.state()
     tol = 1e-8 if prec == 0 else 1e-4
     assert max_abs(m_i[sel], m_f[sel]) < tol and max_abs(c_i[sel], c_f[sel]) < tol
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_body_state_adapters(spe, onp, prec):
+    """BodyStateMeasurement (pose_with_velocity/BodyStateMeasurement.hpp:14-39) for a batch: export rotates
+    the velocity into the navigation frame and extracts the diagonal blocks; import builds the block-diagonal
+    covariance and (re-)initialises the filters."""
+    n = 300
+    mu, cov = spe.synth.pose_initial(n)
+    e = spe.BatchPoseUKF(n, precision=prec); e.initialize(mu, cov)
+    tol = 1e-14 if prec == 0 else 1e-6
+    rec = e.export_body_states()
+    assert rec.shape == (n, 49) and max_abs(rec, onp.body_state_export(mu, cov)) <= tol
+    part = e.export_body_states(first=17, count=5)
+    assert max_abs(part, rec[17:22]) == 0
+    e2 = spe.BatchPoseUKF(n, precision=prec)
+    e2.import_body_states(rec[:200])
+    m2, c2, init = e2.state()
+    mo, co = onp.body_state_import(rec[:200])
+    assert init[:200].all() and not init[200:].any()
+    assert max_abs(m2[:200], mo) <= tol and max_abs(c2[:200], co) <= tol
+    assert (e2.last_measurement_time()[:200] == 0).all()
+    with pytest.raises(spe.UkfbError):
+        spe.BatchOrientationUKF(4, 1.0, 1.0, 0.5).export_body_states()

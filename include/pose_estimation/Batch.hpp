@@ -52,6 +52,15 @@ public:
     void integrateMixedMeasurements(const int32_t* model, const double* z, const double* Q) { check(ukfb_update_mixed(engine, model, z, Q)); }
     /** fused predictionStep + integrateMeasurement in one launch */
     void cycle(double delta_t, int model, const double* z, const double* Q) { check(ukfb_cycle(engine, delta_t, model, z, Q)); }
+    /** fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]); ts < 0: no sample, model < 0: predict only */
+    void cycleFromSampleTimes(const int64_t* ts_us, const int32_t* model, const double* z, const double* Q) { check(ukfb_cycle_timestamps(engine, ts_us, model, z, Q)); }
+    /** time-ordered asynchronous stream of samples in any arrival order (the batched stream aligner); returns the number of launches */
+    int64_t processEvents(int64_t n_events, const int64_t* filter, const int64_t* ts_us, const int32_t* model, const double* z, const double* Q)
+    {
+        int64_t rounds = 0;
+        check(ukfb_process_events(engine, n_events, filter, ts_us, model, z, Q, NULL, &rounds));
+        return rounds;
+    }
     std::vector<uint32_t> status()
     {
         std::vector<uint32_t> st(static_cast<size_t>(cap), 0u);

@@ -199,6 +199,25 @@ int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const
 int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
                    const void* Q_dev);
 
+/* fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]) per filter, one launch.
+ * ts_us[i] < 0: filter i has no sample in this call (untouched, status INACTIVE);
+ * model[i] < 0: prediction only.  Host arrays [capacity] / device arrays in engine precision. */
+int ukfb_cycle_timestamps(ukfb_engine* e, const int64_t* ts_us, const int32_t* meas_model, const double* z, const double* Q);
+int ukfb_cycle_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev, const int32_t* meas_model_dev, const void* z_dev,
+                              const void* Q_dev);
+
+/* ---- time-ordered asynchronous measurement stream ------------------------------------------ */
+/* What Rock's stream aligner (drivers/aggregator, manifest.xml:14) does for one filter, for a batch:
+ * n_events samples (filter index, timestamp, model id, z[3], Q[3][3]) arrive in ANY order.  Per filter
+ * they are applied in timestamp order (stable for equal stamps), each as
+ * predictionStepFromSampleTime(ts) followed by integrateMeasurement(model) (model < 0: prediction
+ * only).  Filters are independent, so the r-th sample of every filter forms round r and each round
+ * is one fused launch.  After the call ukfb_get_status returns, per filter, the OR of its status
+ * words over all rounds; status_or / rounds (may be NULL) receive the batch-wide OR and the number
+ * of launches. */
+int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter, const int64_t* ts_us,
+                        const int32_t* meas_model, const double* z, const double* Q, uint32_t* status_or, int64_t* rounds);
+
 /* ---- measurement of the engine itself ---------------------------------------------------- */
 /* name, dynamic LDS bytes per workgroup, filters per workgroup and grid size of the kernel the
  * most recent predict/update/cycle call launched (for profiles/ and bench.py) */

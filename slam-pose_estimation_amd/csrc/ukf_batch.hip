@@ -228,6 +228,26 @@ template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t
     return UKFB_OK;
 }
 
+// event queue helpers: scatter one round of samples into the dense per-filter staging arrays
+template <class T>
+__global__ void scatter_events_kernel(const int64_t* filt, const int64_t* ts, const int32_t* meas, const T* z, const T* Q,
+                                      int64_t n, int64_t* ts_dense, int32_t* meas_dense, T* z_dense, T* Q_dense) {
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const int64_t f = filt[i];
+    ts_dense[f] = ts[i];
+    meas_dense[f] = meas[i];
+    for (int k = 0; k < 3; ++k) z_dense[f * 3 + k] = z[i * 3 + k];
+    for (int k = 0; k < 9; ++k) Q_dense[f * 9 + k] = Q[i * 9 + k];
+}
+// OR the status words of the round into the accumulator; filters without a sample in this round contribute
+// nothing (their word is the INACTIVE marker only)
+__global__ void accumulate_status_kernel(const uint32_t* st, const int64_t* ts_dense, uint32_t* acc, int64_t n) {
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    if (ts_dense[i] >= 0) acc[i] |= st[i];
+}
+
 __global__ void or_reduce_kernel(const uint32_t* st, int64_t n, uint32_t* out) {
     uint32_t v = 0;
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
@@ -733,6 +753,117 @@ int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const
     int rc = stage_measurements(e, z, Q, nullptr, nullptr);
     if (rc) return rc;
     return ukfb_cycle_dev(e, dt, meas_model, nullptr, e->z_stage, e->Q_stage);
+}
+
+int ukfb_cycle_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev, const int32_t* meas_model_dev, const void* z_dev,
+                              const void* Q_dev) {
+    if (!e || !ts_us_dev || !meas_model_dev || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.do_update = true;
+    r.ts_dev = ts_us_dev;
+    r.meas_dev = meas_model_dev;
+    r.z_dev = z_dev;
+    r.Q_dev = Q_dev;
+    return launch(e, r);
+}
+
+int ukfb_cycle_timestamps(ukfb_engine* e, const int64_t* ts_us, const int32_t* meas_model, const double* z, const double* Q) {
+    if (!e || !ts_us || !meas_model) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = stage_measurements(e, z, Q, meas_model, nullptr);
+    if (rc) return rc;
+    rc = upload_raw(e, e->ts_stage, ts_us, size_t(e->cap));
+    if (rc) return rc;
+    return ukfb_cycle_timestamps_dev(e, e->ts_stage, e->meas_stage, e->z_stage, e->Q_stage);
+}
+
+// ---- time-ordered asynchronous measurement stream -------------------------------------------------
+int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter, const int64_t* ts_us,
+                        const int32_t* meas_model, const double* z, const double* Q, uint32_t* status_or, int64_t* rounds) {
+    if (!e || n_events < 0 || (n_events > 0 && (!filter || !ts_us || !meas_model || !z || !Q)))
+        return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events: bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (status_or) *status_or = 0;
+    if (rounds) *rounds = 0;
+    if (n_events == 0) return UKFB_OK;
+    for (int64_t i = 0; i < n_events; ++i)
+        if (filter[i] < 0 || filter[i] >= e->cap || ts_us[i] < 0)
+            return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
+    // per filter: stable time order; the rank of a sample within its filter is its round
+    std::vector<int64_t> order(static_cast<size_t>(n_events), 0);
+    for (int64_t i = 0; i < n_events; ++i) order[size_t(i)] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        if (filter[a] != filter[b]) return filter[a] < filter[b];
+        return ts_us[a] < ts_us[b];
+    });
+    std::vector<int64_t> round_of(static_cast<size_t>(n_events), 0);
+    int64_t nrounds = 0;
+    for (int64_t k = 0, run = 0; k < n_events; ++k) {
+        run = (k > 0 && filter[order[size_t(k)]] == filter[order[size_t(k - 1)]]) ? run + 1 : 0;
+        round_of[size_t(k)] = run;
+        nrounds = std::max(nrounds, run + 1);
+    }
+    // samples grouped by round (counting sort), packed for one upload
+    std::vector<int64_t> start(static_cast<size_t>(nrounds) + 1, 0);
+    for (int64_t k = 0; k < n_events; ++k) ++start[size_t(round_of[size_t(k)]) + 1];
+    for (int64_t r = 0; r < nrounds; ++r) start[size_t(r) + 1] += start[size_t(r)];
+    const size_t ne = static_cast<size_t>(n_events);
+    std::vector<int64_t> pos(start.begin(), start.end() - 1);
+    std::vector<int64_t> pf(ne, 0), pt(ne, 0);
+    std::vector<int32_t> pm(ne, 0);
+    std::vector<double> pz(ne * 3, 0.0), pq(ne * 9, 0.0);
+    for (int64_t k = 0; k < n_events; ++k) {
+        const int64_t src = order[size_t(k)], dst = pos[size_t(round_of[size_t(k)])]++;
+        pf[size_t(dst)] = filter[src];
+        pt[size_t(dst)] = ts_us[src];
+        pm[size_t(dst)] = meas_model[src];
+        std::memcpy(&pz[size_t(dst) * 3], z + src * 3, 3 * sizeof(double));
+        std::memcpy(&pq[size_t(dst) * 9], Q + src * 9, 9 * sizeof(double));
+    }
+    int64_t *d_f = nullptr, *d_t = nullptr;
+    int32_t* d_m = nullptr;
+    void *d_z = nullptr, *d_q = nullptr;
+    uint32_t* d_acc = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_f), size_t(n_events) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n_events) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_m), size_t(n_events) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&d_z, size_t(n_events) * 3 * e->tsize));
+    HIP_TRY(hipMalloc(&d_q, size_t(n_events) * 9 * e->tsize));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_acc), size_t(e->cap) * sizeof(uint32_t)));
+    int rc = upload_raw(e, d_f, pf.data(), pf.size());
+    if (!rc) rc = upload_raw(e, d_t, pt.data(), pt.size());
+    if (!rc) rc = upload_raw(e, d_m, pm.data(), pm.size());
+    if (!rc) rc = upload(e, d_z, 0, pz.data(), pz.size());
+    if (!rc) rc = upload(e, d_q, 0, pq.data(), pq.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_acc, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
+    const int cap_blocks = int((e->cap + 255) / 256);
+    for (int64_t r = 0; r < nrounds; ++r) {
+        const int64_t lo = start[size_t(r)], cnt = start[size_t(r) + 1] - lo;
+        HIP_TRY(hipMemsetAsync(e->ts_stage, 0xFF, size_t(e->cap) * sizeof(int64_t), e->stream));     // -1: no sample
+        HIP_TRY(hipMemsetAsync(e->meas_stage, 0xFF, size_t(e->cap) * sizeof(int32_t), e->stream));   // -1: no measurement
+        const int blocks = int((cnt + 255) / 256);
+        if (e->prec == UKFB_F64)
+            hipLaunchKernelGGL(scatter_events_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, d_f + lo, d_t + lo, d_m + lo,
+                               static_cast<const double*>(d_z) + lo * 3, static_cast<const double*>(d_q) + lo * 9, cnt,
+                               e->ts_stage, e->meas_stage, static_cast<double*>(e->z_stage), static_cast<double*>(e->Q_stage));
+        else
+            hipLaunchKernelGGL(scatter_events_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, d_f + lo, d_t + lo, d_m + lo,
+                               static_cast<const float*>(d_z) + lo * 3, static_cast<const float*>(d_q) + lo * 9, cnt,
+                               e->ts_stage, e->meas_stage, static_cast<float*>(e->z_stage), static_cast<float*>(e->Q_stage));
+        rc = ukfb_cycle_timestamps_dev(e, e->ts_stage, e->meas_stage, e->z_stage, e->Q_stage);
+        if (rc) return rc;
+        hipLaunchKernelGGL(accumulate_status_kernel, dim3(cap_blocks), dim3(256), 0, e->stream, e->status, e->ts_stage, d_acc,
+                           e->cap);
+    }
+    HIP_TRY(hipMemcpyAsync(e->status, d_acc, size_t(e->cap) * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    void* frees[] = {d_f, d_t, d_m, d_z, d_q, d_acc};
+    for (void* b : frees) HIP_TRY(hipFree(b));
+    if (rounds) *rounds = nrounds;
+    if (status_or) return ukfb_get_status_summary(e, status_or);
+    return UKFB_OK;
 }
 
 // ---- measurement of the engine ------------------------------------------------------------------

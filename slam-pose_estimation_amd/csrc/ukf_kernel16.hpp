@@ -326,21 +326,22 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     T dtT = T(0);
     if constexpr (DO_PREDICT) {
         double dt;
-        bool first = false;
+        bool first = false, noev = false;
         if (a.ts) {   // uniform
             const int64_t last = a.last_ts[fc], ts = a.ts[fc];
-            first = (last == 0);
-            dt = first ? 0.0 : double(ts - last) / 1000000.0;
-            if (live && l == 0 && (first || dt > a.min_dt)) a.last_ts[fc] = ts;
+            noev = ts < 0;                       // event streams: this filter has no sample in this call
+            first = (last == 0) && !noev;
+            dt = (first || noev) ? 0.0 : double(ts - last) / 1000000.0;
+            if (live && l == 0 && !noev && (first || dt > a.min_dt)) a.last_ts[fc] = ts;
         } else {
             dt = a.dt ? a.dt[fc] : a.dt_uniform;
         }
         const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
         const uint32_t code = first ? ST_SKIPPED_FIRST_TS
                                     : (neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u)));
-        st |= live ? code : 0u;
-        p_error = live && !first && (neg || (!small && large));
-        do_p = live && code == 0u;
+        st |= (live && !noev) ? code : 0u;
+        p_error = live && !first && !noev && (neg || (!small && large));
+        do_p = live && !noev && code == 0u;
         dtT = T(dt);
     }
     bool do_u = false;

@@ -44,6 +44,7 @@ EXPORTS = [
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
     "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
+    "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events",
 ]
 BODY_STATE_SCALARS = 49
 
@@ -293,6 +294,29 @@ class BatchUKF:
     def cycle_dev(self, dt: float, meas_model_uniform: int, z_dev, Q_dev, meas_model_dev=None):
         _chk(self._lib.ukfb_cycle_dev(self._h, C.c_double(dt), C.c_int(meas_model_uniform), _devptr(meas_model_dev),
                                       _devptr(z_dev), _devptr(Q_dev)), "ukfb_cycle_dev")
+
+    def cycle_timestamps(self, ts_us, meas_model, z, Q):
+        """Fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]); ts < 0: no sample."""
+        t = np.ascontiguousarray(ts_us, dtype=np.int64).reshape(self.capacity)
+        m = np.ascontiguousarray(meas_model, dtype=np.int32).reshape(self.capacity)
+        z = _f64(z, (self.capacity, 3)); Q = _f64(Q, (self.capacity, 3, 3))
+        _chk(self._lib.ukfb_cycle_timestamps(self._h, t.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             m.ctypes.data_as(C.POINTER(C.c_int32)), _pd(z), _pd(Q)),
+             "ukfb_cycle_timestamps")
+
+    def process_events(self, filter_index, ts_us, meas_model, z, Q):
+        """Time-ordered asynchronous measurement stream (any arrival order).  Returns (status_or, rounds)."""
+        f = np.ascontiguousarray(filter_index, dtype=np.int64).reshape(-1)
+        n = f.size
+        t = np.ascontiguousarray(ts_us, dtype=np.int64).reshape(n)
+        m = np.ascontiguousarray(meas_model, dtype=np.int32).reshape(n)
+        z = _f64(z, (n, 3)); Q = _f64(Q, (n, 3, 3))
+        st, rounds = C.c_uint32(0), C.c_int64(0)
+        _chk(self._lib.ukfb_process_events(self._h, C.c_int64(n), f.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           t.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           m.ctypes.data_as(C.POINTER(C.c_int32)), _pd(z), _pd(Q), C.byref(st),
+                                           C.byref(rounds)), "ukfb_process_events")
+        return int(st.value), int(rounds.value)
 
     # ---- measurement of the engine
     def last_launch_info(self):

@@ -262,3 +262,61 @@ def test_body_state_adapters(spe, onp, prec):
     assert (e2.last_measurement_time()[:200] == 0).all()
     with pytest.raises(spe.UkfbError):
         spe.BatchOrientationUKF(4, 1.0, 1.0, 0.5).export_body_states()
+
+
+def test_time_ordered_event_stream(spe, oracle, onp):
+    """ukfb_process_events: samples arrive in arbitrary order; per filter they must be applied in timestamp
+    order, each as predictionStepFromSampleTime + integrateMeasurement (or prediction only), exactly like
+    a sequential per-filter replay with the oracle (stream-aligner semantics)."""
+    rng = np.random.default_rng(11)
+    n = 23
+    mu, cov = spe.synth.pose_initial(n)
+    R = spe.synth.pose_default_process_noise()
+    ev = []   # (filter, ts, model, z, Q)
+    for f in range(n):
+        k = int(rng.integers(0, 6))          # 0..5 samples per filter (some filters get none)
+        t = 1_000_000 + np.cumsum(rng.integers(1_000, 50_000, size=k))
+        for j in range(k):
+            model = int(rng.choice([-1, 0, 1, 2, 3, 4, 5, 6, 7, 8]))
+            Q = 0.01 * (np.eye(3) + 0.1 * np.diag(rng.uniform(0, 1, 3)))
+            ev.append([f, int(t[j]), model, rng.normal(size=3) * 0.1, Q])
+    # consistent measurements: perturb the initial sub-state (values only matter for determinism)
+    for e_ in ev:
+        if e_[2] >= 0:
+            e_[3] = spe.synth.pose_measurement_for_model(mu[e_[0]:e_[0] + 1], np.array([e_[2]]), e_[3][None])[0]
+    # duplicate timestamp on one filter (stable order) and a late-arriving older sample (negative dt -> error bit)
+    ev.append([2, 1_000_500, 0, mu[2, :3] + 0.01, 0.01 * np.eye(3)])
+    ev.append([2, 1_000_500, 4, mu[2, 7:10] - 0.01, 0.01 * np.eye(3)])
+    perm = rng.permutation(len(ev))
+    shuffled = [ev[i] for i in perm]
+    eng = spe.BatchPoseUKF(n); eng.initialize(mu, cov)
+    st_or, rounds = eng.process_events([e_[0] for e_ in shuffled], [e_[1] for e_ in shuffled], [e_[2] for e_ in shuffled],
+                                       np.stack([e_[3] for e_ in shuffled]), np.stack([e_[4] for e_ in shuffled]))
+    m_g, c_g, _ = eng.state(); st_g = eng.status(); last_g = eng.last_measurement_time()
+    # sequential replay with the oracle
+    m_o, c_o = mu.copy(), cov.copy()
+    last = np.zeros(n, dtype=np.int64); st_o = np.zeros(n, dtype=np.uint32)
+    per_filter = {}
+    for idx in np.argsort([e_[1] for e_ in shuffled], kind="stable"):
+        per_filter.setdefault(shuffled[idx][0], []).append(shuffled[idx])
+    max_events = 0
+    for f, lst in per_filter.items():
+        max_events = max(max_events, len(lst))
+        for (_, ts, model, z, Q) in lst:
+            nl, dt, gs = oracle.gate_timestamps(np.array([ts]), last[f:f + 1])
+            last[f] = nl[0]; st_o[f] |= gs[0]
+            if gs[0] == 0:
+                a, b, s1 = oracle.pose_predict(m_o[f:f + 1], c_o[f:f + 1], R, None, None, dt)
+                m_o[f], c_o[f] = a[0], b[0]; st_o[f] |= s1[0]
+            if gs[0] & (onp.ST_ERR_NEG_DT | onp.ST_ERR_DT_TOO_LARGE):
+                st_o[f] |= onp.ST_INACTIVE if model >= 0 else 0
+                continue                      # the reference's exception aborts the sample's callback
+            if model >= 0:
+                a, b, s2 = oracle.pose_update(m_o[f:f + 1], c_o[f:f + 1], model, z[None], Q[None])
+                m_o[f], c_o[f] = a[0], b[0]; st_o[f] |= s2[0]
+            else:
+                st_o[f] |= onp.ST_INACTIVE
+    assert rounds == max_events
+    assert (last_g == last).all()
+    assert max_abs(m_g, m_o) <= 1e-9 and max_abs(c_g, c_o) <= 1e-9
+    assert (st_g == st_o).all() and st_or == int(np.bitwise_or.reduce(st_o))

@@ -140,6 +140,10 @@ template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layo
 // scheduling fence: keeps the machine scheduler from hoisting the next phase's loads / ALU work
 // across this point (it otherwise trades ~2x the registers for ILP and ends up spilling)
 UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
+// Keeps a loaded value live in a VGPR so that "cond ? loaded : other" stays a v_cndmask; without it the
+// compiler sinks the LDS load into an exec-masked branch (s_and_saveexec / s_cbranch_execz per element).
+UKFB_DEV void keep(float& x) { asm volatile("" : "+v"(x)); }
+UKFB_DEV void keep(double& x) { asm volatile("" : "+v"(x)); }
 
 template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
     bool good = true;
@@ -262,7 +266,6 @@ UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const
         // acceleration branch (PoseUKF.cpp:190-191): raw noise with block(6,6,3,3) = 2 acc.cov, prepared by
         // the host (ukf_batch.hip: rebuild_racc) whenever the noise or acc.cov changes
         vacc = Racc[r * D + c];
-        if (__all(pin.use_acc)) return vacc;   // wave-uniform fast path
     }
     const T rn = Rn[r * D + c];
     const int o = (r < 3 && c < 3) ? 0 : ((r >= 3 && r < 6 && c >= 3 && c < 6) ? 3 : -1);
@@ -317,25 +320,73 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     const bool has_pair = l < D;       // lane owns the sigma pair of column l
     const bool has_ctr = l == D;       // lane owns the centre point
 
+    // ---- prologue: EVERY per-filter stream is requested before the first dependent instruction, so the kernel
+    // pays the HBM latency once.  Optional streams (null pointer) are read from a substitute address that is
+    // always valid and the value is dropped by a select - a branch here would serialise the round trips.
+    const uint8_t init_b = a.initialised[fc];
+    int64_t last_l = 0, ts_l = 0;
+    double dt_l = 0.0;
+    if constexpr (DO_PREDICT) {
+        const int64_t* tsp = a.ts ? (a.ts + fc) : (a.last_ts + fc);
+        const double* dtp = a.dt ? (a.dt + fc) : reinterpret_cast<const double*>(a.last_ts + fc);
+        last_l = a.last_ts[fc];
+        ts_l = *tsp;
+        dt_l = *dtp;
+    }
+    int32_t mid_l = 0;
+    uint8_t act_b = 1;
+    if constexpr (DO_UPDATE) {
+        const int32_t* mp = a.meas ? (a.meas + fc) : reinterpret_cast<const int32_t*>(a.status + fc);
+        const uint8_t* ap = a.active ? (a.active + fc) : (a.initialised + fc);
+        mid_l = *mp;
+        act_b = *ap;
+    }
+    T cov_l[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int e = l + G * t;
+        cov_l[t] = a.cov[fc * PK + ((e < PK) ? e : (PK - 1))];
+    }
+    const T mu_l = a.mu[fc * S + ((l < S) ? l : (S - 1))];
+    ProcIn<T> pin;
+    if constexpr (DO_PREDICT) {
+        const T* pa = a.in_a ? (a.in_a + fc * 3) : (a.mu + fc * S);
+        const T* pb = a.in_b ? (a.in_b + fc * 3) : (a.mu + fc * S);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pin.a[k] = pa[k];
+            pin.w[k] = pb[k];
+        }
+    }
+    T zq_l = T(0);
+    if constexpr (DO_UPDATE) {
+        const T* zp = (l < 3) ? (a.z + fc * 3 + l) : (a.Q + fc * 9 + ((l < 12) ? (l - 3) : 0));
+        zq_l = *zp;
+    }
+
+    // ---- stage the filter in LDS: packed covariance, mean, measurement
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int e = l + G * t;
+        PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = cov_l[t];
+    }
+    MUS[(l < S) ? l : (LY::DUM - LY::MUS)] = mu_l;
+    if constexpr (DO_UPDATE) ZQ[(l < 12) ? l : (LY::DUM - LY::ZQ)] = zq_l;
+
     uint32_t st = ST_OK;
-    const bool live = fvalid && (a.initialised[fc] != 0);
+    const bool live = fvalid && (init_b != 0);
     st |= (fvalid && !live) ? ST_UNINITIALISED : 0u;
 
     // ---- time gate (UnscentedKalmanFilter.hpp:83-125)
-    bool do_p = false, p_error = false;
+    bool do_p = false, p_error = false, ts_store = false;
     T dtT = T(0);
     if constexpr (DO_PREDICT) {
-        double dt;
-        bool first = false, noev = false;
-        if (a.ts) {   // uniform
-            const int64_t last = a.last_ts[fc], ts = a.ts[fc];
-            noev = ts < 0;                       // event streams: this filter has no sample in this call
-            first = (last == 0) && !noev;
-            dt = (first || noev) ? 0.0 : double(ts - last) / 1000000.0;
-            if (live && l == 0 && !noev && (first || dt > a.min_dt)) a.last_ts[fc] = ts;
-        } else {
-            dt = a.dt ? a.dt[fc] : a.dt_uniform;
-        }
+        const bool use_ts = a.ts != nullptr;
+        const bool noev = use_ts && (ts_l < 0);      // event streams: this filter has no sample in this call
+        const bool first = use_ts && (last_l == 0) && !noev;
+        const double dt_ts = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
+        const double dt = use_ts ? dt_ts : (a.dt ? dt_l : a.dt_uniform);
+        ts_store = use_ts && live && l == 0 && !noev && (first || dt > a.min_dt);
         const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
         const uint32_t code = first ? ST_SKIPPED_FIRST_TS
                                     : (neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u)));
@@ -343,46 +394,35 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         p_error = live && !first && !noev && (neg || (!small && large));
         do_p = live && !noev && code == 0u;
         dtT = T(dt);
+        pin.dt = dtT;
+        pin.ninv_tau_g = a.ninv_tau_g;
+        pin.ninv_tau_a = a.ninv_tau_a;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pin.earth[k] = a.earth[k];
+            pin.a[k] = a.in_a ? pin.a[k] : T(NAN);
+            pin.w[k] = a.in_b ? pin.w[k] : T(0);
+        }
+        pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
     }
     bool do_u = false;
     int mid = -1;
     if constexpr (DO_UPDATE) {
-        mid = a.meas ? a.meas[fc] : a.meas_uniform;
-        const bool act = M::meas_valid(mid) && (a.active ? a.active[fc] != 0 : true);
+        mid = a.meas ? mid_l : a.meas_uniform;
+        const bool act = M::meas_valid(mid) && (a.active ? act_b != 0 : true);
         do_u = live && act && !p_error;
         st |= (live && !do_u) ? ST_INACTIVE : 0u;
     }
-
-    // ---- stage the filter: packed covariance and mean -> LDS
-#pragma unroll
-    for (int t = 0; t < EPL; ++t) {
-        const int e = l + G * t;
-        const T v = a.cov[fc * PK + ((e < PK) ? e : (PK - 1))];
-        PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = v;
-    }
-    {
-        const T v = a.mu[fc * S + ((l < S) ? l : (S - 1))];
-        MUS[(l < S) ? l : (LY::DUM - LY::MUS)] = v;
-    }
     wsync();
+    if constexpr (DO_PREDICT) {
+        if (ts_store) a.last_ts[fc] = ts_l;   // after every load of the prologue has been issued
+    }
 
     bool p_commit = false, u_commit = false;
 
     // =========================================================================== predict
     if constexpr (DO_PREDICT) {
         if (__any(do_p)) {
-            ProcIn<T> pin;
-            pin.dt = dtT;
-            pin.ninv_tau_g = a.ninv_tau_g;
-            pin.ninv_tau_a = a.ninv_tau_a;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                pin.earth[k] = a.earth[k];
-                pin.a[k] = a.in_a ? a.in_a[fc * 3 + k] : T(NAN);
-                pin.w[k] = a.in_b ? a.in_b[fc * 3 + k] : T(0);
-            }
-            pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
-
             T xp[S], xm[S], ref[S];
             bool ok;
             {
@@ -495,11 +535,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 bool active = n2 > a.mean_tol * a.mean_tol;
                 int it = 0;
                 if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
-#ifdef X_NO_LOOP
-                while (false) {
-#else
                 while (__any(active)) {
-#endif
                     T rp[3], rm[3], mr[3];
                     rot_minus(qp, qr, rp);
                     rot_minus(qm, qr, rm);
@@ -553,16 +589,40 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             const bool tile_ok = r0 >= 0;
             const int tr0 = tile_ok ? r0 : 0;
-            T acc[TR][TC];
+            // shaped process noise of this lane's tile: with a plain table (Pose acceleration branch) it is
+            // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
+            // (it would hold 2 x TR x TC products in flight across the loop)
+            constexpr bool NZ_EARLY = (M::MODEL == 0);
+            T acc[TR][TC], nz[TR][TC];
+            {
+                const T* Rn = a.Rn + fc * a.Rn_stride;
+                const T* Ra = a.Racc + fc * a.Rn_stride;
+                const bool all_acc = NZ_EARLY && __all(pin.use_acc);
 #pragma unroll
-            for (int i = 0; i < TR; ++i)
+                for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                for (int j = 0; j < TC; ++j) acc[i][j] = T(0);
-#ifdef X_UNROLL1
-#pragma unroll 1
-#else
+                    for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = nz[i2][j2] = T(0);
+                if (all_acc) {   // wave-uniform: plain table reads, all in flight together
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) {
+                            const int r = tr0 + i2, c = c0 + j2;
+                            const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+                            nz[i2][j2] = Ra[rc * D + cc];
+                        }
+                } else if (NZ_EARLY) {
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) {
+                            const int r = tr0 + i2, c = c0 + j2;
+                            const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+                            nz[i2][j2] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
+                        }
+                }
+            }
 #pragma unroll 5
-#endif
             for (int i = 0; i < N; ++i) {
                 T vr[TR], vc[TC];
 #pragma unroll
@@ -578,7 +638,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             p_commit = pc;
             st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
             st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
-            const T* Rn = a.Rn + fc * a.Rn_stride;
 #pragma unroll
             for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
@@ -586,12 +645,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     const int r = tr0 + i2, c = c0 + j2;
                     const bool w = p_commit && tile_ok && r < D && c <= r;
                     const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
-#ifdef X_NO_NOISE
-                    const T val = T(0.5) * acc[i2][j2];
-#else
-                    const T val = fma(T(0.5), acc[i2][j2], process_noise_entry16<T, M>(Rn, a.Racc + fc * a.Rn_stride, ROT, a, pin, rc, cc));
-#endif
-                    PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = val;
+                    const T nv = NZ_EARLY ? nz[i2][j2]
+                                          : process_noise_entry16<T, M>(a.Rn + fc * a.Rn_stride, a.Racc + fc * a.Rn_stride, ROT, a, pin, rc, cc);
+                    PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = fma(T(0.5), acc[i2][j2], nv);
                 }
             // a gated / failed predict must leave the ORIGINAL state for the update and the commit:
             // re-stage it from HBM (rare path, wave-uniform guard)
@@ -612,12 +668,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     // =========================================================================== update
     if constexpr (DO_UPDATE) {
         if (__any(do_u)) {
-            {
-                const int zi = (l < 3) ? l : 0, qi = (l >= 3 && l < 12) ? (l - 3) : 0;
-                const T zv = a.z[fc * 3 + zi], qv = a.Q[fc * 9 + qi];
-                ZQ[(l < 12) ? l : (LY::DUM - LY::ZQ)] = (l < 3) ? zv : qv;
-            }
-            wsync();
             T zin[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) zin[k] = ZQ[k];
@@ -659,10 +709,12 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     used[k] = sk != 15;
                     const int si = used[k] ? sk : 0;
                     ti[k] = (si < Q) ? si : (si - 1);
-                    const T m0 = MUS[si];
+                    T m0 = MUS[si];
+                    keep(m0);
                     innov[k] = used[k] ? (zin[k] - m0) : T(0);
                     const int hi = la > ti[k] ? la : ti[k], lo = la > ti[k] ? ti[k] : la;
-                    const T sx = PKS[hi * (hi + 1) / 2 + lo];
+                    T sx = PKS[hi * (hi + 1) / 2 + lo];
+                    keep(sx);
                     cx[k] = used[k] ? sx : T(0);
                 }
 #pragma unroll
@@ -671,8 +723,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     for (int c = 0; c < 3; ++c) {
                         const int hi = ti[r] > ti[c] ? ti[r] : ti[c], lo = ti[r] > ti[c] ? ti[c] : ti[r];
                         const T pad = (r == c) ? T(1) : T(0);
-                        const T sv = PKS[hi * (hi + 1) / 2 + lo] + ZQ[3 + r * 3 + c];
-                        Sm[r * 3 + c] = (used[r] && used[c]) ? sv : pad;
+                        T sp = PKS[hi * (hi + 1) / 2 + lo], sq = ZQ[3 + r * 3 + c];
+                        keep(sp);
+                        keep(sq);
+                        Sm[r * 3 + c] = (used[r] && used[c]) ? (sp + sq) : pad;
                     }
             }
             if (__any(need_q)) {
@@ -770,7 +824,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const T pad = (r == c) ? T(1) : T(0);
-                            Qm[r * 3 + c] = (r >= m || c >= m) ? pad : ZQ[3 + r * 3 + c];
+                            T qv = ZQ[3 + r * 3 + c];
+                            keep(qv);
+                            Qm[r * 3 + c] = (r >= m || c >= m) ? pad : qv;
                         }
                     T u6[6];
 #pragma unroll
@@ -920,7 +976,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         for (int s6 = 0; s6 < 6; ++s6) rrv = (hi * (hi + 1) / 2 + lo == s6) ? rr[s6] : rrv;
                         v = lrot ? rrv : cr[bi];
                     } else {
-                        const T other = WK[b * 4 + li];   // cross term computed by lane b for rotation column li
+                        T other = WK[b * 4 + li];   // cross term computed by lane b for rotation column li
+                        keep(other);
                         v = lrot ? other : srow2[b];
                     }
                     const bool w = u_commit && has_pair && b <= l;

@@ -30,6 +30,8 @@
 // LDS stores select a dummy address instead of branching, rare math fall-backs are wave-uniform.
 #pragma once
 
+#include <type_traits>
+
 #include "ukf_kernel.hpp"
 
 namespace ukfb {
@@ -45,6 +47,27 @@ template <int CTRL> UKFB_DEV double dpp_mov(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, int(unsigned(b)), CTRL, 0xF, 0xF, true);
     const int hi = __builtin_amdgcn_update_dpp(0, int(unsigned(b >> 32)), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32));
+}
+// value held by lane C of this lane's row (row_newbcast: one VALU move, no LDS round trip)
+template <int C> UKFB_DEV float row_bcast(float v) { return dpp_mov<0x150 + C>(v); }
+template <int C> UKFB_DEV double row_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + C, 0xF, 0xF, true); }
+// acc += (lane C's src) * m as ONE instruction (the compiler keeps v_mov_dpp + v_fmac apart).  Inline asm is
+// opaque to the hazard recognizer: callers put dpp_hazard_fence(src) between the producer of `src` and the
+// first use (VALU write -> DPP read needs 2 wait states); volatile keeps that order.
+template <int C> UKFB_DEV void fmac_bcast(float& acc, float src, float m) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
+}
+template <int C> UKFB_DEV void fmac_bcast(double& acc, double src, double m) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
+}
+UKFB_DEV void dpp_hazard_fence(float src) { asm volatile("s_nop 1" ::"v"(src)); }
+UKFB_DEV void dpp_hazard_fence(double src) { asm volatile("s_nop 1" ::"v"(src)); }
+// compile-time loop (DPP controls are immediates)
+template <int B, int E, class F> UKFB_DEV void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
 // xor-1, xor-2 inside quads, then mirrored halves: every lane of the row ends with the same bits.
 template <class T> UKFB_DEV T row_allreduce(T v) {
@@ -109,31 +132,39 @@ template <class T> struct MT<OrientM<T>> {
 template <class T, class M> struct Layout16 {
     static constexpr int VEC = 16 / int(sizeof(T));
     static constexpr int D = M::D, S = M::S, N = 2 * D + 1, PK = D * (D + 1) / 2;
-    static constexpr int LS = (D + VEC - 1) / VEC * VEC;   // column stride of the factor = row stride of the deltas
-    static constexpr int PKP = (PK + VEC - 1) / VEC * VEC;
+    // column stride of the factor = row stride of the deltas.  Lane l addresses row / column l, so the stride
+    // in dwords decides the bank conflicts of every lane-strided access (measured on gfx950: 32 banks for b32,
+    // 64 for b64/b128 accesses - tools/lds_probe.hip).
+    // 14 scalars = 14 / 28 dwords: lanes 0..15 fall on distinct banks in both precisions (a stride of 12 or 16
+    // scalars repeats after 8 resp. 2 lanes; measured +3..10 % on the fused cycle).
+    static constexpr int LS = 14;
+    // row stride of the W / K / cross-term exchange (4 used), conflict-free for the same reason
+    static constexpr int WS = 4;
+    static constexpr int al(int x) { return (x + VEC - 1) / VEC * VEC; }
+    static constexpr int PKP = al(PK);
     static constexpr int LC = 0;                            // D*LS : unscaled factor columns
     static constexpr int DXT = 0;                           // N*LS : delta table (aliases LC and PKS)
-    static constexpr int PKS = D * LS;                      // PKP  : packed covariance staging
-    static constexpr int MISC = N * LS;
+    static constexpr int PKS = al(D * LS);                  // PKP  : packed covariance staging
+    static constexpr int MISC = al(N * LS);
     static constexpr int MUS = MISC;                        // 16 : mean staging
     static constexpr int ROT = MISC + 16;                   // 12 : rotation matrix of the mean
     static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
-    static constexpr int WK = MISC + 40;                    // D*4 (<= 56): W / K / cross-term exchange
-    static constexpr int DUM = MISC + 96;                   // 16 : sink for lane-predicated stores
-    static constexpr int PF_RAW = MISC + 112;
+    static constexpr int WK = MISC + 40;                    // D*WS (<= 80): W / K / cross-term exchange
+    static constexpr int DUM = MISC + 120;                  // 16 : sink for lane-predicated stores
+    static constexpr int PF_RAW = MISC + 136;
     // the four slices of a wavefront must not start on the same LDS bank (measured: a slice stride that is
     // a multiple of 32 dwords costs 25-50 %: every broadcast read becomes a 4-way conflict)
     static constexpr int PF = PF_RAW + (((PF_RAW * int(sizeof(T)) / 4) % 32 == 0) ? 2 * VEC : 0);
-    static_assert(D * LS + PKP <= N * LS, "packed staging must fit behind the factor");
-    static_assert(D * 4 <= 56 && PF % VEC == 0 && LS <= 16 && S <= 16, "scratch layout");
+    static_assert(PKS + PKP <= MISC, "packed staging must fit behind the factor");
+    static_assert(D * WS <= 80 && PF % VEC == 0 && LS >= D && LS <= 16 && S <= 16, "scratch layout");
 };
 
 template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layout16<T, M>::PF * int(sizeof(T)); }
 
 // ---------------------------------------------------------------------------------------------
-// Cholesky: lane l < D holds row l (entries 0..l) in a[].  Column k is published UNSCALED
-// (v_l = a_l[k], pivot included) with one LDS write; every lane reads pivot + the column entries it
-// needs, derives rs = 1/sqrt(pivot) itself and updates its trailing row.  L[c][k] = Lc[k*LS+c]*rs_k
+// Cholesky: lane l < D holds row l (entries 0..l) in a[].  The factorisation itself runs on DPP row
+// broadcasts (lane c's A[c][k] for the trailing update, lane k's pivot); column k is published UNSCALED
+// (v_l = a_l[k], pivot included) with one LDS write for the consumers.  L[c][k] = Lc[k*LS+c]*rs_k
 // for c >= k (entries above the diagonal are garbage and must be masked by the consumer).
 // Returns this lane's rs_l (lane l < D); ok = all pivots > 0.  `dum`: offset of the store sink.
 // ---------------------------------------------------------------------------------------------
@@ -147,24 +178,21 @@ UKFB_DEV void keep(double& x) { asm volatile("" : "+v"(x)); }
 
 template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
     bool good = true;
-    // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
-    Lc[(l < D) ? l : dum] = (l >= 0) ? a[0] : T(0);
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        wsync();
-        const T akk = Lc[k * LS + k];
+    static_for<0, D>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
+        Lc[(l < D) ? (k * LS + l) : dum] = (l >= k) ? a[k] : T(0);
+        const T akk = row_bcast<k>(a[k]);
         good = good && (akk > T(0));
-        const T t = a[k] * fast_rcp(akk);   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
-        if (k + 1 < D) {
-            // software pipeline: finish column k+1 first and publish it, the rest of the trailing update
-            // overlaps the LDS round trip of that store
-            a[k + 1] = fma(-t, Lc[k * LS + k + 1], a[k + 1]);
-            Lc[(l < D) ? ((k + 1) * LS + l) : dum] = (l >= k + 1) ? a[k + 1] : T(0);
+        const T nt = -(a[k] * fast_rcp(akk));   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
+        if constexpr (k + 1 < D) {
+            dpp_hazard_fence(a[k]);
+            static_for<k + 1, D>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                fmac_bcast<c>(a[c], a[k], nt);   // a[c] -= t * A[c][k], lane c holds A[c][k]
+            });
         }
-#pragma unroll
-        for (int c = k + 2; c < D; ++c) a[c] = fma(-t, Lc[k * LS + c], a[c]);
-        sfence();
-    }
+    });
     ok = good;
     wsync();
     const int lc = (l < D) ? l : (D - 1);
@@ -298,7 +326,7 @@ template <class T, class M, bool DO_PREDICT, bool DO_UPDATE>
 __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
-    constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
+    constexpr int LS = LY::LS, WS = LY::WS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
     constexpr int G = 16, FPW = 4, EPL = (PK + G - 1) / G;
     static_assert(D + 1 <= G && S <= G, "a filter must fit one DPP row");
 
@@ -511,8 +539,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             // Euclidean part of the mean is final: write those delta columns now and drop the registers
             wsync();  // every lane is done with the factor columns (they alias the table)
             {
-                T* rowp = has_p ? (DXT + (has_ctr ? (2 * D) : (2 * l)) * LS) : DUMP;
-                T* rowm = has_m ? (DXT + (2 * l + 1) * LS) : DUMP;
+                // rows 0..D: +column l / centre, rows D+1..2D: -column l (lane stride LS: see Layout16::LS)
+                T* rowp = has_p ? (DXT + l * LS) : DUMP;
+                T* rowm = has_m ? (DXT + (D + 1 + l) * LS) : DUMP;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     if (s < Q) { rowp[s] = xp[s] - ref[s]; rowm[s] = xm[s] - ref[s]; }
@@ -562,8 +591,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 T rp[3], rm[3];
                 rot_minus(qp, qr, rp);
                 rot_minus(qm, qr, rm);
-                T* rowp = has_p ? (DXT + (has_ctr ? (2 * D) : (2 * l)) * LS) : DUMP;
-                T* rowm = has_m ? (DXT + (2 * l + 1) * LS) : DUMP;
+                // rows 0..D: +column l / centre, rows D+1..2D: -column l (lane stride LS: see Layout16::LS)
+                T* rowp = has_p ? (DXT + l * LS) : DUMP;
+                T* rowm = has_m ? (DXT + (D + 1 + l) * LS) : DUMP;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { rowp[RT + k] = rp[k]; rowm[RT + k] = rm[k]; }
                 T* dst = (pc && l == 0) ? MUS : DUMP;
@@ -693,7 +723,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             // Measurement statistics: S (innovation covariance), cx (row l of Sigma_xz), innovation.
             bool ok1 = true, zconv = true;
             T Sm[9], cx[3], innov[3];
-            T* wrow = has_pair ? (WK + l * 4) : DUMP;
+            T* wrow = has_pair ? (WK + l * WS) : DUMP;
             const int la = has_pair ? l : (D - 1);
             if (MT<M>::HAS_EUCLID_MEAS) {
                 // Sub-state selections (PoseUKF.cpp:7-26,35-69) are LINEAR in the tangent, and the unscented
@@ -853,7 +883,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 for (int j = 0; j < D; ++j) {
                     const T v = Lc[j * LS + la];   // zero for j > la
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) cg[k] = fma(v, WK[j * 4 + k], cg[k]);
+                    for (int k = 0; k < 3; ++k) cg[k] = fma(v, WK[j * WS + k], cg[k]);
                     if ((j & 3) == 3) sfence();
                 }
                 ok1 = need_q ? okg : ok1;
@@ -899,10 +929,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 load_row<T, D>(PKS, l, arow2);
 #pragma unroll
                 for (int b = 0; b < D; ++b) {
-                    const T kb0 = WK[b * 4], kb1 = WK[b * 4 + 1], kb2 = WK[b * 4 + 2];
+                    const T kb0 = WK[b * WS], kb1 = WK[b * WS + 1], kb2 = WK[b * WS + 2];
                     arow2[b] -= (KSr[0] * kb0 + KSr[1] * kb1 + KSr[2] * kb2);
                     srow2[b] = arow2[b];
-                    d0[b] = WK[b * 4 + 3];
+                    d0[b] = WK[b * WS + 3];
                     if ((b & 3) == 3) sfence();
                 }
                 rs2 = chol16<T, D, LS>(arow2, Lc, l, LY::DUM - LY::LC, ok2);
@@ -946,7 +976,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             for (int j = 0; j < D; ++j) {
                 const T v = Lc[j * LS + la];   // zero for j > la
 #pragma unroll
-                for (int k = 0; k < 3; ++k) cr[k] = fma(v, WK[j * 4 + k], cr[k]);
+                for (int k = 0; k < 3; ++k) cr[k] = fma(v, WK[j * WS + k], cr[k]);
                 if ((j & 3) == 3) sfence();
             }
             wsync();  // W rows consumed
@@ -976,7 +1006,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         for (int s6 = 0; s6 < 6; ++s6) rrv = (hi * (hi + 1) / 2 + lo == s6) ? rr[s6] : rrv;
                         v = lrot ? rrv : cr[bi];
                     } else {
-                        T other = WK[b * 4 + li];   // cross term computed by lane b for rotation column li
+                        T other = WK[b * WS + li];   // cross term computed by lane b for rotation column li
                         keep(other);
                         v = lrot ? other : srow2[b];
                     }

@@ -96,6 +96,7 @@ template <class T> struct MT<PoseM<T>> {
     static constexpr unsigned long long SEL2 = nib(0, 2) | nib(1, 15) | nib(2, 15) | nib(3, 15) | nib(4, 9) | nib(5, 15) |
                                                nib(6, 15) | nib(7, 15) | nib(8, 12);
     static constexpr bool HAS_EUCLID_MEAS = true;
+    static constexpr int ZCOLS = 6;   // tangent columns that can move an orientation-dependent measurement (p, q)
     // orientation-dependent measurement (model id 3, PoseUKF.cpp:28-33): the quaternion itself.
     // qp / qm / q0: orientation of the +column, -column and centre sigma point.
     UKFB_DEV static void gen_measure(const T (&qp)[4], const T (&qm)[4], const T (&q0)[4], const T*, const T*, T,
@@ -108,6 +109,7 @@ template <class T> struct MT<OrientM<T>> {
     static constexpr int Q = 0, RT = 0, TR = 3, TC = 3;
     static constexpr unsigned long long SEL0 = 0, SEL1 = 0, SEL2 = 0;
     static constexpr bool HAS_EUCLID_MEAS = false;
+    static constexpr int ZCOLS = 6;   // body velocity q^-1 v reads the orientation (0..2) and the velocity (3..5)
     // velocityMeasurementModel (OrientationUKF.cpp:34-39): q.inverse() * v for the three sigma points;
     // the velocity (stored 4..6, tangent 3..5) comes straight from the mean staging and the factor column
     UKFB_DEV static void body_vel(const T (&q)[4], const T (&v)[3], T (&z)[4]) {
@@ -484,14 +486,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             sfence();
             process_fast((M*)nullptr, xm, pin);
             sfence();
-            {   // propagated centre point: lane D publishes it, every lane starts the mean from it
-                T* dst = has_ctr ? WK : DUMP;
+            // propagated centre point (lane D): every lane starts the mean from it
 #pragma unroll
-                for (int s = 0; s < S; ++s) dst[s] = xp[s];
-                wsync();
-#pragma unroll
-                for (int s = 0; s < S; ++s) ref[s] = WK[s];
-            }
+            for (int s = 0; s < S; ++s) ref[s] = row_bcast<D>(xp[s]);
             const bool has_p = has_pair || has_ctr, has_m = has_pair;
             const T wp = has_p ? T(1) : T(0), wm = has_m ? T(1) : T(0);
 
@@ -875,16 +872,22 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 }
                 sfence();
                 // ---- cross covariance: Cxz[a][c] = sum_l L[a][l] * 0.5 (dz+_l - dz-_l)[c]
-#pragma unroll
-                for (int k = 0; k < 3; ++k) wrow[k] = T(0.5) * rs * (dzp[k] - dzm[k]);
-                wsync();
+                // (columns >= ZCOLS do not move the measurement: dz+ == dz- bit for bit, their W row is zero)
                 T cg[3] = {T(0), T(0), T(0)};
+                {
+                    T w[3];
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    const T v = Lc[j * LS + la];   // zero for j > la
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) cg[k] = fma(v, WK[j * WS + k], cg[k]);
-                    if ((j & 3) == 3) sfence();
+                    for (int k = 0; k < 3; ++k) {
+                        w[k] = T(0.5) * rs * (dzp[k] - dzm[k]);
+                        dpp_hazard_fence(w[k]);
+                    }
+                    static_for<0, MT<M>::ZCOLS>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const T v = Lc[j * LS + la];   // zero for j > la
+                        fmac_bcast<j>(cg[0], w[0], v);
+                        fmac_bcast<j>(cg[1], w[1], v);
+                        fmac_bcast<j>(cg[2], w[2], v);
+                    });
                 }
                 ok1 = need_q ? okg : ok1;
                 zconv = need_q ? zc : zconv;
@@ -914,11 +917,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 for (int c = 0; c < 3; ++c) KSr[c] = Kr[0] * Sm[c] + Kr[1] * Sm[3 + c] + Kr[2] * Sm[6 + c];
             }
             const T del = Kr[0] * innov[0] + Kr[1] * innov[1] + Kr[2] * innov[2];
-            wsync();  // W rows consumed by every lane before they become K rows
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wrow[k] = Kr[k];
-            wrow[3] = del;
-            wsync();
             sfence();
             // ---- Sigma' = Sigma - (K S) K^T, row l on lane l; delta on every lane
             T srow2[D], d0[D];
@@ -927,14 +925,18 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             {
                 T arow2[D];
                 load_row<T, D>(PKS, l, arow2);
-#pragma unroll
-                for (int b = 0; b < D; ++b) {
-                    const T kb0 = WK[b * WS], kb1 = WK[b * WS + 1], kb2 = WK[b * WS + 2];
-                    arow2[b] -= (KSr[0] * kb0 + KSr[1] * kb1 + KSr[2] * kb2);
+                const T nks[3] = {-KSr[0], -KSr[1], -KSr[2]};
+                dpp_hazard_fence(Kr[0]);
+                dpp_hazard_fence(Kr[1]);
+                dpp_hazard_fence(Kr[2]);
+                static_for<0, D>([&](auto bc) {   // lane b holds row b of the gain and delta[b]
+                    constexpr int b = decltype(bc)::value;
+                    fmac_bcast<b>(arow2[b], Kr[0], nks[0]);
+                    fmac_bcast<b>(arow2[b], Kr[1], nks[1]);
+                    fmac_bcast<b>(arow2[b], Kr[2], nks[2]);
                     srow2[b] = arow2[b];
-                    d0[b] = WK[b * WS + 3];
-                    if ((b & 3) == 3) sfence();
-                }
+                    d0[b] = row_bcast<b>(del);
+                });
                 rs2 = chol16<T, D, LS>(arow2, Lc, l, LY::DUM - LY::LC, ok2);
                 wsync();
             }
@@ -966,20 +968,24 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     const T loc = has_pair ? fma(rp[r], rp[c], rm[r] * rm[c]) : T(0);
                     rr[r * (r + 1) / 2 + c] = T(0.5) * row_allreduce(loc);
                 }
-            wsync();  // K rows consumed
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wrow[k] = T(0.5) * rs2 * (rp[k] - rm[k]);
-            wsync();
-            // cross terms of row l with the three rotation columns
+            // cross terms of row l with the three rotation columns.  Columns past the rotation block have a zero
+            // rotation part (lower-triangular factor): r+ == r- bit for bit, their W row is zero.
             T cr[3] = {T(0), T(0), T(0)};
+            {
+                T w[3];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const T v = Lc[j * LS + la];   // zero for j > la
-#pragma unroll
-                for (int k = 0; k < 3; ++k) cr[k] = fma(v, WK[j * WS + k], cr[k]);
-                if ((j & 3) == 3) sfence();
+                for (int k = 0; k < 3; ++k) {
+                    w[k] = T(0.5) * rs2 * (rp[k] - rm[k]);
+                    dpp_hazard_fence(w[k]);
+                }
+                static_for<0, RT + 3>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const T v = Lc[j * LS + la];   // zero for j > la
+                    fmac_bcast<j>(cr[0], w[0], v);
+                    fmac_bcast<j>(cr[1], w[1], v);
+                    fmac_bcast<j>(cr[2], w[2], v);
+                });
             }
-            wsync();  // W rows consumed
 #pragma unroll
             for (int k = 0; k < 3; ++k) wrow[k] = cr[k];
             wsync();

@@ -62,58 +62,41 @@ UKFB_DEV double fast_rcp(double x) {
 }
 UKFB_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Near-minimax polynomials (Chebyshev fits computed with mpmath at 50 digits; max abs error quoted) for
+//   cos(sqrt(y)), sin(sqrt(y))/sqrt(y) on 0 <= y <= 0.62   and   atan(sqrt(u))/sqrt(u) on 0 <= u <= 0.07.
+// Three terms shorter than the Taylor series of the same accuracy; coefficients c0..cn, Horner form.
 template <class T> struct Poly;
 template <> struct Poly<double> {
-    // cos(sqrt(y)) = sum (-1)^k y^k/(2k)!, sinc(sqrt(y)) = sum (-1)^k y^k/(2k+1)!  (|y| <= 0.62: < 1 ulp)
-    static UKFB_DEV void cos_sinc(double y, double& c, double& s) {
-        double pc = 1.0 / 121645100408832000.0;   // 1/19! (sinc k=9)
-        double qc = -1.0 / 6402373705728000.0;    // -1/18! (cos k=9)
-        qc = fma(qc, y, 1.0 / 20922789888000.0);      pc = fma(-pc, y, 1.0 / 355687428096000.0);   // 1/16!, 1/17!
-        qc = fma(qc, y, -1.0 / 87178291200.0);        pc = fma(pc, y, -1.0 / 1307674368000.0);     // -1/14!, -1/15!
-        qc = fma(qc, y, 1.0 / 479001600.0);           pc = fma(pc, y, 1.0 / 6227020800.0);         // 1/12!, 1/13!
-        qc = fma(qc, y, -1.0 / 3628800.0);            pc = fma(pc, y, -1.0 / 39916800.0);          // -1/10!, -1/11!
-        qc = fma(qc, y, 1.0 / 40320.0);               pc = fma(pc, y, 1.0 / 362880.0);             // 1/8!, 1/9!
-        qc = fma(qc, y, -1.0 / 720.0);                pc = fma(pc, y, -1.0 / 5040.0);              // -1/6!, -1/7!
-        qc = fma(qc, y, 1.0 / 24.0);                  pc = fma(pc, y, 1.0 / 120.0);                // 1/4!, 1/5!
-        qc = fma(qc, y, -0.5);                        pc = fma(pc, y, -1.0 / 6.0);                 // -1/2!, -1/3!
-        c = fma(qc, y, 1.0);
-        s = fma(pc, y, 1.0);
-    }
-    // atan(sqrt(u))/sqrt(u) = sum (-1)^k u^k/(2k+1), 0 <= u <= 0.07 (14 terms; even/odd split)
-    static UKFB_DEV double atan_ratio(double u) {
-        const double u2 = u * u;
-        double e = 1.0 / 25.0, o = -1.0 / 27.0;
-        e = fma(e, u2, 1.0 / 21.0);  o = fma(o, u2, -1.0 / 23.0);
-        e = fma(e, u2, 1.0 / 17.0);  o = fma(o, u2, -1.0 / 19.0);
-        e = fma(e, u2, 1.0 / 13.0);  o = fma(o, u2, -1.0 / 15.0);
-        e = fma(e, u2, 1.0 / 9.0);   o = fma(o, u2, -1.0 / 11.0);
-        e = fma(e, u2, 1.0 / 5.0);   o = fma(o, u2, -1.0 / 7.0);
-        e = fma(e, u2, 1.0);         o = fma(o, u2, -1.0 / 3.0);
-        return fma(o, u, e);
-    }
+    static constexpr int NC = 6, NS = 6, NA = 8;
+    static constexpr double COS[NC + 1] = {0.999999999999999951, -0.499999999999992276, 0.0416666666664673017,
+                                           -0.00138888888695903017, 0.000024801578404008521, -2.7555212612292537e-7,
+                                           2.06292036185570243e-9};                                    // 4.9e-17
+    static constexpr double SINC[NS + 1] = {0.999999999999999997, -0.166666666666666151, 0.00833333333332002843,
+                                            -0.000198412698283910677, 2.75573132865827307e-6, -2.50507027741921191e-8,
+                                            1.58939017348049994e-10};                                  // 3.3e-18
+    static constexpr double ATAN[NA + 1] = {0.999999999999999988, -0.333333333333304925, 0.199999999989156351,
+                                            -0.142857141260715088, 0.111110993100731619, -0.0909041735889935631,
+                                            0.0768020126708874696, -0.0649096002386012782, 0.0446824258353296505};  // 1.2e-17
     static constexpr double Y_SMALL = 0.62, U_SMALL = 0.07;
 };
 template <> struct Poly<float> {
-    static UKFB_DEV void cos_sinc(float y, float& c, float& s) {
-        float qc = 1.0f / 479001600.0f, pc = 1.0f / 6227020800.0f;   // 1/12!, 1/13!
-        qc = fmaf(qc, y, -1.0f / 3628800.0f);   pc = fmaf(pc, y, -1.0f / 39916800.0f);
-        qc = fmaf(qc, y, 1.0f / 40320.0f);      pc = fmaf(pc, y, 1.0f / 362880.0f);
-        qc = fmaf(qc, y, -1.0f / 720.0f);       pc = fmaf(pc, y, -1.0f / 5040.0f);
-        qc = fmaf(qc, y, 1.0f / 24.0f);         pc = fmaf(pc, y, 1.0f / 120.0f);
-        qc = fmaf(qc, y, -0.5f);                pc = fmaf(pc, y, -1.0f / 6.0f);
-        c = fmaf(qc, y, 1.0f);
-        s = fmaf(pc, y, 1.0f);
-    }
-    static UKFB_DEV float atan_ratio(float u) {
-        const float u2 = u * u;
-        float e = 1.0f / 13.0f, o = -1.0f / 15.0f;
-        e = fmaf(e, u2, 1.0f / 9.0f);   o = fmaf(o, u2, -1.0f / 11.0f);
-        e = fmaf(e, u2, 1.0f / 5.0f);   o = fmaf(o, u2, -1.0f / 7.0f);
-        e = fmaf(e, u2, 1.0f);          o = fmaf(o, u2, -1.0f / 3.0f);
-        return fmaf(o, u, e);
-    }
+    static constexpr int NC = 4, NS = 3, NA = 3;
+    static constexpr float COS[NC + 1] = {1.0f, -0.4999999961f, 0.04166661593f, -0.001388659487f, 2.437769412e-5f};  // 4.9e-11
+    static constexpr float SINC[NS + 1] = {0.9999999969f, -0.1666665043f, 0.008332022568f, -0.0001950219494f};         // 3.1e-9
+    static constexpr float ATAN[NA + 1] = {0.9999999814f, -0.3333247988f, 0.1993845199f, -0.1284461816f};              // 1.9e-8
     static constexpr float Y_SMALL = 0.62f, U_SMALL = 0.07f;
 };
+template <class T, int N> UKFB_DEV T horner(const T (&c)[N + 1], T x) {
+    T r = c[N];
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) r = fma(r, x, c[k]);
+    return r;
+}
+template <class T> UKFB_DEV void poly_cos_sinc(T y, T& c, T& s) {
+    c = horner<T, Poly<T>::NC>(Poly<T>::COS, y);
+    s = horner<T, Poly<T>::NS>(Poly<T>::SINC, y);
+}
+template <class T> UKFB_DEV T poly_atan_ratio(T u) { return horner<T, Poly<T>::NA>(Poly<T>::ATAN, u); }
 
 template <class T> struct TwoPi;
 template <> struct TwoPi<double> {
@@ -146,7 +129,7 @@ template <class T> UKFB_DEV void cos_sinc_fast(T y, T& c, T& s) {
         ratio = big ? xr * rs : T(1);                    // sin(x)/x = sinc(xr) * xr/x
     }
     T c1, s1;
-    Poly<T>::cos_sinc(yy, c1, s1);
+    poly_cos_sinc(yy, c1, s1);
     const T c2 = fma(T(2) * c1, c1, T(-1)), s2 = s1 * c1;    // angle x2
     const T c4 = fma(T(2) * c2, c2, T(-1)), s4 = s2 * c2;    // angle x4
     c = small ? c1 : (big ? c4 : c2);
@@ -171,7 +154,7 @@ template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
     const T w = q[3];
     const T rw = fast_rcp(w);
     const T u = v2 * rw * rw;
-    T s = T(2) * rw * Poly<T>::atan_ratio(u);
+    T s = T(2) * rw * poly_atan_ratio(u);
     const bool big = !(u <= Poly<T>::U_SMALL);
     if (__any(big)) {
         const T n2 = fma(w, w, v2);
@@ -184,7 +167,7 @@ template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
         const T q3 = T(1) + t2;
         const T r3 = fast_rcp(T(1) + q3 * fast_rsqrt(q3));
         const T t3 = t2 * r3 * r3;                       // tan^2(phi/8) <= 0.0396
-        const T sb = T(16) * (r1 * r2) * r3 * Poly<T>::atan_ratio(t3);
+        const T sb = T(16) * (r1 * r2) * r3 * poly_atan_ratio(t3);
         s = big ? ((w < T(0)) ? -sb : sb) : s;
     }
     r[0] = s * q[0]; r[1] = s * q[1]; r[2] = s * q[2];

@@ -116,24 +116,32 @@ UKFB_DEV float m_abs(float x) { return __builtin_fabsf(x); }
 // their inlined large-argument paths cost ~100 live registers per call site.
 template <class T> UKFB_DEV void cos_sinc_fast(T y, T& c, T& s) {
     const bool small = y <= Poly<T>::Y_SMALL;
+    const bool any_large = __any(!small);   // wave-uniform: the doubling steps below are skipped on the common path
     const bool big = !(y <= T(4) * Poly<T>::Y_SMALL);
-    T yy = small ? y : T(0.25) * y;
+    T yy = y;
     T ratio = T(1);
-    if (__any(big)) {
-        const T rs = fast_rsqrt(big ? y : T(1));         // 1/x
-        const T x = y * rs;
-        const T k = m_rint(x * TwoPi<T>::inv);
-        T xr = fma(-k, TwoPi<T>::hi, x);
-        xr = fma(-k, TwoPi<T>::lo, xr);                  // |xr| <= pi
-        yy = big ? (xr * xr) * T(0.0625) : yy;           // (xr/4)^2 <= (pi/4)^2
-        ratio = big ? xr * rs : T(1);                    // sin(x)/x = sinc(xr) * xr/x
+    if (any_large) {
+        yy = small ? y : T(0.25) * y;
+        if (__any(big)) {
+            const T rs = fast_rsqrt(big ? y : T(1));         // 1/x
+            const T x = y * rs;
+            const T k = m_rint(x * TwoPi<T>::inv);
+            T xr = fma(-k, TwoPi<T>::hi, x);
+            xr = fma(-k, TwoPi<T>::lo, xr);                  // |xr| <= pi
+            yy = big ? (xr * xr) * T(0.0625) : yy;           // (xr/4)^2 <= (pi/4)^2
+            ratio = big ? xr * rs : T(1);                    // sin(x)/x = sinc(xr) * xr/x
+        }
     }
     T c1, s1;
     poly_cos_sinc(yy, c1, s1);
-    const T c2 = fma(T(2) * c1, c1, T(-1)), s2 = s1 * c1;    // angle x2
-    const T c4 = fma(T(2) * c2, c2, T(-1)), s4 = s2 * c2;    // angle x4
-    c = small ? c1 : (big ? c4 : c2);
-    s = small ? s1 : (big ? s4 * ratio : s2);
+    c = c1;
+    s = s1;
+    if (any_large) {
+        const T c2 = fma(T(2) * c1, c1, T(-1)), s2 = s1 * c1;    // angle x2
+        const T c4 = fma(T(2) * c2, c2, T(-1)), s4 = s2 * c2;    // angle x4
+        c = small ? c1 : (big ? c4 : c2);
+        s = small ? s1 : (big ? s4 * ratio : s2);
+    }
 }
 
 // exp / log with the fast primitives (same maps as so3_exp / so3_log below)
@@ -202,17 +210,15 @@ template <class T> UKFB_DEV void quat_mul(const T (&a)[4], const T (&b)[4], T (&
 
 // Eigen _transformVector: v + w*uv + vec x uv, uv = 2 (vec x v)
 template <class T> UKFB_DEV void quat_rotate(const T (&q)[4], const T (&v)[3], T (&r)[3]) {
-    T ux = q[QY] * v[2] - q[QZ] * v[1];
-    T uy = q[QZ] * v[0] - q[QX] * v[2];
-    T uz = q[QX] * v[1] - q[QY] * v[0];
-    ux += ux; uy += uy; uz += uz;
+    const T ux = q[QY] * v[2] - q[QZ] * v[1];   // uv / 2
+    const T uy = q[QZ] * v[0] - q[QX] * v[2];
+    const T uz = q[QX] * v[1] - q[QY] * v[0];
     const T cx = q[QY] * uz - q[QZ] * uy;
     const T cy = q[QZ] * ux - q[QX] * uz;
     const T cz = q[QX] * uy - q[QY] * ux;
-    const T r0 = v[0] + q[QW] * ux + cx;
-    const T r1 = v[1] + q[QW] * uy + cy;
-    const T r2 = v[2] + q[QW] * uz + cz;
-    r[0] = r0; r[1] = r1; r[2] = r2;
+    r[0] = fma(T(2), fma(q[QW], ux, cx), v[0]);
+    r[1] = fma(T(2), fma(q[QW], uy, cy), v[1]);
+    r[2] = fma(T(2), fma(q[QW], uz, cz), v[2]);
 }
 
 // Eigen toRotationMatrix, row-major

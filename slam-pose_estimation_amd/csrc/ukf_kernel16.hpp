@@ -180,10 +180,12 @@ UKFB_DEV void keep(double& x) { asm volatile("" : "+v"(x)); }
 
 template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
     bool good = true;
+    // lanes >= D carry a copy of row D-1 (load_row clamps) and store the same values to the same addresses
+    const int lw = (l < D) ? l : (D - 1);
     static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
-        Lc[(l < D) ? (k * LS + l) : dum] = (l >= k) ? a[k] : T(0);
+        Lc[k * LS + lw] = (l >= k) ? a[k] : T(0);
         const T akk = row_bcast<k>(a[k]);
         good = good && (akk > T(0));
         const T nt = -(a[k] * fast_rcp(akk));   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
@@ -513,10 +515,36 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     else if (s >= Q + 4) loc[s - 1] = fma(wm, xm[s] - ref[s], wp * (xp[s] - ref[s]));
                 }
                 T md[D];
+                if constexpr (sizeof(T) == 8) {
+                    // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) table region:
+                    // lane c sums component c over the 16 lanes and publishes the mean
+                    constexpr int TS = 18;   // row stride: b128 rows of lanes 0..D-1 fall on distinct banks
+                    static_assert(D * TS + D <= N * LS, "transposition buffer must fit the table region");
+                    T* TB = DXT;
 #pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    md[c] = row_allreduce(loc[c]) * (T(1) / T(N));
-                    n2 += md[c] * md[c];
+                    for (int c = 0; c < D; ++c) TB[c * TS + l] = loc[c];
+                    wsync();
+                    const int cl = (l < D) ? l : (D - 1);
+                    T part[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) part[j] = TB[cl * TS + j];
+#pragma unroll
+                    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                        for (int j = 0; j < w; ++j) part[j] += part[j + w];
+                    TB[D * TS + cl] = part[0] * (T(1) / T(N));
+                    wsync();
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        md[c] = TB[D * TS + c];
+                        n2 += md[c] * md[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        md[c] = row_allreduce(loc[c]) * (T(1) / T(N));
+                        n2 += md[c] * md[c];
+                    }
                 }
                 // reference [+] mean delta
                 {

@@ -45,8 +45,8 @@ class _DevArray:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--filters", type=int, default=TOTAL_FILTERS, help="total filters over all ranks")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
@@ -198,9 +198,14 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
+    t_launch = time.perf_counter()
     kernel_ms_total = eng.timer_end()
+    t_event = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("UKFB_BENCH_DEBUG"):
+        print("launch %.2f ms, event sync %.2f ms, fence %.2f ms, gpu %.2f ms" % (
+            (t_launch - t0) * 1e3, (t_event - t_launch) * 1e3, (t0 + elapsed - t_event) * 1e3, kernel_ms_total), file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -264,6 +264,21 @@ void set_error(const char* what, hipError_t err) {
 }
 }  // namespace ukfb
 
+// Waiting by polling: hipEventSynchronize / hipStreamSynchronize sleep on an interrupt and were measured to
+// wake up to ~55 ms late on a loaded host (1 run in 5), which is longer than the work being waited for.
+static hipError_t wait_stream_polling(hipStream_t s) {
+    hipError_t r;
+    while ((r = hipStreamQuery(s)) == hipErrorNotReady) {
+    }
+    return r;
+}
+static hipError_t wait_event_polling(hipEvent_t ev) {
+    hipError_t r;
+    while ((r = hipEventQuery(ev)) == hipErrorNotReady) {
+    }
+    return r;
+}
+
 extern "C" {
 
 const char* ukfb_last_error(void) { return g_last_error.c_str(); }
@@ -382,7 +397,7 @@ int ukfb_get_config(const ukfb_engine* e, ukfb_config* cfg) {
 
 int ukfb_sync(ukfb_engine* e) {
     if (!e) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(wait_stream_polling(e->stream));
     return UKFB_OK;
 }
 
@@ -888,7 +903,7 @@ int ukfb_timer_begin(ukfb_engine* e) {
 int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms) {
     if (!e || !elapsed_ms) return UKFB_ERR_INVALID_ARG;
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(wait_event_polling(e->ev1));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
     return UKFB_OK;
 }

@@ -78,6 +78,14 @@ template <class T> UKFB_DEV T row_allreduce(T v) {
     return v;
 }
 
+// K row sums at once (DPP butterflies).  An LDS transposition (lane c adds up component c) was measured for
+// fp64, where a butterfly costs 12 VALU: it pays for the 12-wide mean of the prediction only; for K <= 6 the
+// two extra LDS round trips cost more than the saved instructions (Orient fp64 -2.5 %).
+template <class T, int K> UKFB_DEV void row_allreduce_n(T (&v)[K], T*, int) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) v[c] = row_allreduce(v[c]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // manifold traits for the tuned kernel
 // ---------------------------------------------------------------------------------------------
@@ -349,6 +357,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     T* ZQ = base + LY::ZQ;
     T* WK = base + LY::WK;
     T* DUMP = base + LY::DUM;
+    T* RED = nullptr;
     const bool has_pair = l < D;       // lane owns the sigma pair of column l
     const bool has_ctr = l == D;       // lane owns the centre point
 
@@ -461,7 +470,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 T mu_r[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
-                {   // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81)
+                // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose
+                // acceleration branch does not rotate its noise (wave-uniform skip)
+                if (M::MODEL != 0 || !__all(pin.use_acc)) {
                     T q[4], rot[9];
                     M::orientation(mu_r, q);
                     quat_to_matrix(q, rot);
@@ -595,9 +606,11 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     rot_minus(qm, qr, rm);
                     T m2 = T(0);
 #pragma unroll
+                    for (int k = 0; k < 3; ++k) mr[k] = fma(wm, rm[k], wp * rp[k]);
+                    row_allreduce_n<T, 3>(mr, RED, l);
+#pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const T loc = fma(wm, rm[k], wp * rp[k]);
-                        mr[k] = row_allreduce(loc) * (T(1) / T(N));
+                        mr[k] *= (T(1) / T(N));
                         m2 += mr[k] * mr[k];
                     }
                     T e[4], nq[4];
@@ -737,14 +750,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             const int m = M::meas_dim(midc);
             const bool so3 = M::meas_is_so3(midc);
             const bool need_q = so3 || (M::MODEL == 1);
-            T zval[4];
-            {
-                T qe[4];
-                so3_exp_fast(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
-#pragma unroll
-                for (int k = 0; k < 3; ++k) zval[k] = so3 ? qe[k] : ((k < m) ? zin[k] : T(0));
-                zval[3] = so3 ? qe[3] : T(0);
-            }
             // Measurement statistics: S (innovation covariance), cx (row l of Sigma_xz), innovation.
             bool ok1 = true, zconv = true;
             T Sm[9], cx[3], innov[3];
@@ -787,6 +792,13 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             if (__any(need_q)) {
                 // Orientation-dependent models (PoseUKF.cpp:28-33, OrientationUKF.cpp:34-39): full sigma-point
                 // path of ukfom::update.  Wave-uniform branch; results are selected per filter below.
+                T zval[4] = {(0 < m) ? zin[0] : T(0), (1 < m) ? zin[1] : T(0), (2 < m) ? zin[2] : T(0), T(0)};
+                if (__any(so3)) {
+                    T qe[4];
+                    so3_exp_fast(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) zval[k] = so3 ? qe[k] : zval[k];
+                }
                 bool okg;
                 T rs;
                 {
@@ -822,9 +834,11 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         rot_minus(z0, zref, r0v);
                         T m2 = T(0);
 #pragma unroll
+                        for (int k = 0; k < 3; ++k) mr[k] = has_pair ? (rp[k] + rm[k]) : T(0);
+                        row_allreduce_n<T, 3>(mr, RED, l);
+#pragma unroll
                         for (int k = 0; k < 3; ++k) {
-                            const T loc = has_pair ? (rp[k] + rm[k]) : T(0);
-                            mr[k] = (row_allreduce(loc) + r0v[k]) * (T(1) / T(N));
+                            mr[k] = (mr[k] + r0v[k]) * (T(1) / T(N));
                             m2 += mr[k] * mr[k];
                         }
                         T e[4], nq[4];
@@ -842,10 +856,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 {
                     T zr[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const T loc = has_pair ? ((zp[k] - z0[k]) + (zm[k] - z0[k])) : T(0);
-                        zr[k] = z0[k] + row_allreduce(loc) * (T(1) / T(N));
-                    }
+                    for (int k = 0; k < 3; ++k) zr[k] = has_pair ? ((zp[k] - z0[k]) + (zm[k] - z0[k])) : T(0);
+                    row_allreduce_n<T, 3>(zr, RED, l);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) zr[k] = z0[k] + zr[k] * (T(1) / T(N));
 #pragma unroll
                     for (int k = 0; k < 3; ++k) zref[k] = so3 ? zref[k] : zr[k];
                 }
@@ -887,10 +901,14 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c <= r; ++c) {
-                            const T loc = has_pair ? fma(dzp[r], dzp[c], dzm[r] * dzm[c]) : T(0);
-                            u6[r * (r + 1) / 2 + c] = T(0.5) * (row_allreduce(loc) + dz0[r] * dz0[c]);
-                        }
+                        for (int c = 0; c <= r; ++c)
+                            u6[r * (r + 1) / 2 + c] = has_pair ? fma(dzp[r], dzp[c], dzm[r] * dzm[c]) : T(0);
+                    row_allreduce_n<T, 6>(u6, RED, l);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c)
+                            u6[r * (r + 1) / 2 + c] = T(0.5) * (u6[r * (r + 1) / 2 + c] + dz0[r] * dz0[c]);
                     Sg[0] = u6[0] + Qm[0];
                     Sg[3] = u6[1] + Qm[3]; Sg[1] = u6[1] + Qm[1];
                     Sg[4] = u6[2] + Qm[4];
@@ -992,10 +1010,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) {
-                    const T loc = has_pair ? fma(rp[r], rp[c], rm[r] * rm[c]) : T(0);
-                    rr[r * (r + 1) / 2 + c] = T(0.5) * row_allreduce(loc);
-                }
+                for (int c = 0; c <= r; ++c) rr[r * (r + 1) / 2 + c] = has_pair ? fma(rp[r], rp[c], rm[r] * rm[c]) : T(0);
+            row_allreduce_n<T, 6>(rr, RED, l);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rr[k] *= T(0.5);
             // cross terms of row l with the three rotation columns.  Columns past the rotation block have a zero
             // rotation part (lower-triangular factor): r+ == r- bit for bit, their W row is zero.
             T cr[3] = {T(0), T(0), T(0)};

@@ -186,20 +186,21 @@ UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
 UKFB_DEV void keep(float& x) { asm volatile("" : "+v"(x)); }
 UKFB_DEV void keep(double& x) { asm volatile("" : "+v"(x)); }
 
-template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
+// KS < D factorises the first KS columns only (consumers that need no more; pivots KS.. are then not checked).
+template <class T, int D, int LS, int KS = D> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
     bool good = true;
     // lanes >= D carry a copy of row D-1 (load_row clamps) and store the same values to the same addresses
     const int lw = (l < D) ? l : (D - 1);
-    static_for<0, D>([&](auto kc) {
+    static_for<0, KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
         Lc[k * LS + lw] = (l >= k) ? a[k] : T(0);
         const T akk = row_bcast<k>(a[k]);
         good = good && (akk > T(0));
         const T nt = -(a[k] * fast_rcp(akk));   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
-        if constexpr (k + 1 < D) {
+        if constexpr (k + 1 < KS) {
             dpp_hazard_fence(a[k]);
-            static_for<k + 1, D>([&](auto cc) {
+            static_for<k + 1, KS>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 fmac_bcast<c>(a[c], a[k], nt);   // a[c] -= t * A[c][k], lane c holds A[c][k]
             });
@@ -207,7 +208,7 @@ template <class T, int D, int LS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int
     });
     ok = good;
     wsync();
-    const int lc = (l < D) ? l : (D - 1);
+    const int lc = (l < KS) ? l : (KS - 1);
     return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l)
 }
 
@@ -804,13 +805,17 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 {
                     T arow[D];
                     load_row<T, D>(PKS, l, arow);
-                    rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, okg);
+                    // Only the first ZCOLS columns of the factor move the measurement.  An indefinite Sigma whose
+                    // first ZCOLS pivots are positive is caught by the complete factorisation of Sigma' below
+                    // (Sigma' <= Sigma), with the same status bit.
+                    rs = chol16<T, D, LS, MT<M>::ZCOLS>(arow, Lc, l, LY::DUM - LY::LC, okg);
                     wsync();
                 }
                 T zp[4], zm[4], z0[4];
                 {
-                    const T w = has_pair ? rs : T(0);
-                    const T* colp = Lc + la * LS;
+                    const bool zcol = l < MT<M>::ZCOLS;
+                    const T w = zcol ? rs : T(0);
+                    const T* colp = Lc + (zcol ? l : (MT<M>::ZCOLS - 1)) * LS;
                     const T q0[4] = {MUS[Q], MUS[Q + 1], MUS[Q + 2], MUS[Q + 3]};
                     const T cr[3] = {colp[RT] * w, colp[RT + 1] * w, colp[RT + 2] * w};
                     T e[4], qp[4], qm[4];

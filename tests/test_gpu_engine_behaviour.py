@@ -172,6 +172,35 @@ def test_failure_statuses_leave_the_filter_untouched(spe, onp):
         spe.BatchPoseUKF(4, lanes_per_filter=48)  # only 16 / 32 / 64
 
 
+def test_indefinite_covariance_in_orientation_dependent_updates(spe, onp, oracle):
+    """The orientation-dependent update factorises only the columns that move the measurement; an indefinite
+    Sigma behind them is still reported (by the complete factorisation of Sigma') and the filter stays put."""
+    s = spe.synth
+    n = 4
+    mo, co = s.orient_initial(n)
+    bad = co.copy(); bad[1, 10, 10] = -1e-3; bad[2, 2, 2] = -1e-3     # pivot 10 is beyond, pivot 2 inside the columns used
+    eo = spe.BatchOrientationUKF(n, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE); eo.initialize(mo, bad)
+    z = np.zeros((n, 3)); Q = np.stack([np.eye(3) * 0.0025] * n)
+    eo.update(spe.MEAS_ORIENT_BODYVEL3, z, Q)
+    st = eo.status()
+    m_o, c_o, st_o = oracle.orient_update(mo, bad, z, Q)
+    assert (st == st_o).all() and st[1] == onp.ST_ERR_CHOLESKY and st[2] == onp.ST_ERR_CHOLESKY and st[0] == 0 and st[3] == 0
+    m, c, _ = eo.state()
+    assert max_abs(m[1:3], mo[1:3]) == 0 and max_abs(c[1:3], 0.5 * (bad[1:3] + bad[1:3].transpose(0, 2, 1))) == 0
+    assert max_abs(m, m_o) <= 1e-9 and max_abs(c, c_o) <= 1e-9
+    # Pose, orientation measurement on SO(3) (PoseUKF.cpp:133-138)
+    mu, cov = s.pose_initial(n)
+    badp = cov.copy(); badp[3, 9, 9] = -1e-3
+    e = spe.BatchPoseUKF(n); e.initialize(mu, badp)
+    zr = np.full((n, 3), 0.01)
+    e.update(spe.MEAS_ORIENT_SO3, zr, Q)
+    st = e.status()
+    m_o, c_o, st_o = oracle.pose_update(mu, badp, spe.MEAS_ORIENT_SO3, zr, Q)
+    assert (st == st_o).all() and st[3] == onp.ST_ERR_CHOLESKY and (st[:3] == 0).all()
+    m, c, _ = e.state()
+    assert max_abs(m[3], mu[3]) == 0 and max_abs(m, m_o) <= 1e-9 and max_abs(c, c_o) <= 1e-9
+
+
 def test_per_filter_process_noise_and_read_back(spe, oracle):
     n = 9
     mu, cov = spe.synth.pose_initial(n)

@@ -6,10 +6,12 @@
 
 One "step" = one fused launch of PoseUKF::predictionStep(dt) on the acceleration branch followed by
 integrateMeasurement(PositionMeasurement) for EVERY filter of the batch.  The
-workload is the configuration the metric is quoted on: 1 048 576 PoseWithVelocity filters, computed in
-fp64 (the reference's own arithmetic type), sharded evenly over the N ranks (no data-path collective:
-filters are independent; RCCL is used once, after the timed region, to gather the means).  Inputs
-(acceleration, measurement, measurement covariance) are resident in HBM before the clock starts.
+workload is the configuration the metric is quoted on: 1 048 576 PoseWithVelocity filters per GPU, computed
+in fp64 (the reference's own arithmetic type).  Filters are independent, so ranks own disjoint filter ranges
+and there is no data-path collective; RCCL is used once, after the timed region, to gather the means.
+Default scaling is WEAK (every rank runs 1 048 576 filters, value = all filters x steps / time);
+--scaling strong shards 1 048 576 filters in total over the ranks instead.  Inputs (acceleration,
+measurement, measurement covariance) are resident in HBM before the clock starts.
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     -- HBM roofline of the fused kernel from ALGORITHMIC bytes
@@ -47,7 +49,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--filters", type=int, default=TOTAL_FILTERS, help="total filters over all ranks")
+    ap.add_argument("--filters", type=int, default=TOTAL_FILTERS,
+                    help="filters per GPU (weak scaling, default) or in total (--scaling strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank runs --filters filters (N x --filters in total); strong: --filters "
+                         "filters are sharded evenly over the ranks (the literal '1 M filters on 1/2/4/8 GPUs')")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,7 +139,8 @@ def main():
 
     prec = spe.F64 if args.precision == "f64" else spe.F32
     tdtype = torch.float64 if prec == spe.F64 else torch.float32
-    first, per = spe.shard_range(args.filters, world, rank)
+    total = args.filters * world if args.scaling == "weak" else args.filters
+    first, per = spe.shard_range(total, world, rank)
 
     # ---- build the shard (host generation in chunks, then resident in HBM)
     CH = 131072
@@ -221,15 +228,15 @@ def main():
             mu_local = mu_local.cpu()
         fence()
         g0 = time.perf_counter()
-        gathered = spe.gather_means(mu_local, args.filters, world, dist)
+        gathered = spe.gather_means(mu_local, total, world, dist)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        assert gathered.shape == (args.filters, S)
+        assert gathered.shape == (total, S)
 
     info = eng.last_launch_info()
     if rank == 0:
         tsize = 8 if prec == spe.F64 else 4
-        value = args.filters * args.steps / elapsed
+        value = total * args.steps / elapsed
         alg_bytes_launch = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * tsize * per
         kernel_ms = kernel_ms_total / args.steps
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
@@ -242,16 +249,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": (f"{args.filters} OrientationState UKF filters, fused predict(gyro+acc, dt=0.01)"
+            "config": {"workload": (f"{total} OrientationState UKF filters, fused predict(gyro+acc, dt=0.01)"
                                     f"+body-velocity update per step, {args.precision}, {per} filters per GPU" if orient else
-                                    f"{args.filters} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)+"
+                                    f"{total} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)+"
                                     + ("per-filter measurement model (9 models, 25 % inactive)" if args.workload == "pose-mixed"
                                        else "PositionMeasurement") + f" update per step, {args.precision}, {per} filters per GPU"),
-                       "filters": args.filters, "filters_per_gpu": per,
+                       "filters": total, "filters_per_gpu": per,
                        "lanes_per_filter": 64 // max(1, info["filters_per_workgroup"]),
                        "parallelism": f"filter-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

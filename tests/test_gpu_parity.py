@@ -148,3 +148,37 @@ def test_pose_trajectory_100_cycles_fp64(spe, oracle):
     m_g, c_g, _ = eng.state()
     assert eng.status_summary() == 0
     assert max_abs(m_g, m_o) <= 1e-9 and max_abs(c_g, c_o) <= 1e-9
+
+
+def test_large_rotations_take_the_fallback_paths(spe, oracle):
+    """Angles far outside the polynomial ranges of the fast exp / log: fast spinning filters (|omega| dt up to
+    ~7 rad, beyond the 2 pi reduction), wide orientation covariances (sigma-point spread ~1 rad, half-angle
+    steps of the log) and orientation measurements ~2.5 rad away from the state.  A quarter of the filters keeps
+    small angles so that wavefronts mix both paths.  Spreads of this size make the UKF itself ill-conditioned
+    (the iterated mean may hit its cap), so the bar here is agreement with the oracle in values AND status."""
+    n = 64
+    rng = np.random.default_rng(12)
+    mu, cov = spe.synth.pose_initial(n)
+    big = np.arange(n) % 4 != 0
+    mu[big, 10:13] = rng.uniform(-40.0, 40.0, (int(big.sum()), 3))          # angular velocity, rad/s
+    for i in np.nonzero(big)[0]:
+        cov[i, 3:6, :] *= 10.0
+        cov[i, :, 3:6] *= 10.0                                              # orientation sigma 0.05 -> 0.5 rad
+    e = spe.BatchPoseUKF(n); e.initialize(mu, cov)
+    R = spe.synth.pose_default_process_noise()
+    e.predict(0.1)
+    m_g, c_g, _ = e.state()
+    m_o, c_o, st_o = oracle.pose_predict(mu, cov, R, None, None, 0.1)
+    assert (e.status() == st_o).all()
+    scale = max(1.0, float(np.abs(c_o).max()))
+    assert max_abs(m_g, m_o) <= 1e-8 and max_abs(c_g, c_o) <= 1e-8 * scale
+    # orientation measurement far from the state: innovation of ~2.5 rad through log
+    z = rng.uniform(-1.0, 1.0, (n, 3)); z *= (2.5 / np.linalg.norm(z, axis=1))[:, None]
+    z[~big] *= 0.01
+    Q = np.stack([np.eye(3) * 0.04] * n)
+    e.update(spe.MEAS_ORIENT_SO3, z, Q)
+    m_g2, c_g2, _ = e.state()
+    m_o2, c_o2, st_o2 = oracle.pose_update(m_o, c_o, spe.MEAS_ORIENT_SO3, z, Q)
+    assert (e.status() == st_o2).all()
+    scale = max(1.0, float(np.abs(c_o2).max()))
+    assert max_abs(m_g2, m_o2) <= 1e-7 and max_abs(c_g2, c_o2) <= 1e-7 * scale

@@ -7,20 +7,22 @@
 //
 //  * lane l < D owns the sigma PAIR mu [+] (+L col l), mu [+] (-L col l): one L column read and one
 //    SO(3) exp serve both points (exp(-v) = conj(exp(v))); lane D owns the centre point.
-//  * manifold means are reduced with a 4-step DPP butterfly (quad_perm, quad_perm, row_half_mirror,
-//    row_mirror) -- no LDS round trip, bit-identical totals on all 16 lanes.  Euclidean components
-//    converge in the first iteration, so later iterations only touch the SO(3) part.
-//  * Cholesky: rows in VGPRs, ONE LDS hop per column (unscaled column + pivot published together,
-//    every lane derives rsqrt(pivot) itself); consumers scale columns on the fly.
+//  * manifold means: 4-step DPP butterfly (quad_perm, quad_perm, row_half_mirror, row_mirror), bit-identical
+//    totals on all 16 lanes; fp64 (12 VALU per butterfly) transposes the 12-wide first iteration through
+//    LDS instead.  Euclidean components converge in the first iteration, later iterations only touch SO(3).
+//  * Cholesky: rows in VGPRs; pivot and column entries travel by DPP row_newbcast fused into the FMA
+//    (v_fmac_*_dpp), no LDS inside the factorisation; each column is published once for the consumers.
+//  * gain rows, delta and cross-term rows are exchanged the same way (row_newbcast), not through LDS.
 //  * covariance recombination 0.5 * sum d d^T is blocked into 16 register tiles (2x3 for D = 12,
 //    3x3 for D = 13) reading the delta table from LDS.
 //  * the update exploits exact identities of the unscented transform instead of recomputing them:
-//    (mu [+] d) [-] mu = d for the state deltas, and in applyDelta the Euclidean block of
-//    0.5 sum (X_i [-] X_0)(..)^T equals L' L'^T = Sigma' entry for entry, so only the rows/columns
-//    of the SO(3) component are re-sampled (through exp/log).  Results differ from the literal
-//    restatement by rounding only (tests/test_gpu_parity.py holds both to 1e-9 / 1e-4).
-//  * LDS per filter: delta table (aliases the factor and the packed-covariance staging) + 112
-//    scalars; 12.9 KB per wavefront in fp64 -> 3 wavefronts per SIMD.
+//    (mu [+] d) [-] mu = d for the state deltas; linear (sub-state) measurements have S, Sigma_xz in closed
+//    form; in applyDelta the Euclidean block of 0.5 sum (X_i [-] X_0)(..)^T equals L' L'^T = Sigma' entry for
+//    entry, so only the rows/columns of the SO(3) component are re-sampled (through exp/log).  Results differ
+//    from the literal restatement by rounding only (tests/test_gpu_parity.py holds both to 1e-9 / 1e-4).
+//  * every per-filter stream is requested in the prologue, before the first dependent instruction.
+//  * LDS per filter: delta table (aliases the factor, the packed-covariance staging and the fp64 mean
+//    transposition) + 136 scalars, row stride 14 (bank-conflict free for lane-strided accesses).
 //
 // TOOLCHAIN NOTE (ROCm 7.2 hipcc, -O2/-O3): when this kernel needed VGPR spills / live-range
 // splits, the compiler placed the copies at the join label of a divergent `if` BEFORE the
@@ -81,7 +83,7 @@ template <class T> UKFB_DEV T row_allreduce(T v) {
 // K row sums at once (DPP butterflies).  An LDS transposition (lane c adds up component c) was measured for
 // fp64, where a butterfly costs 12 VALU: it pays for the 12-wide mean of the prediction only; for K <= 6 the
 // two extra LDS round trips cost more than the saved instructions (Orient fp64 -2.5 %).
-template <class T, int K> UKFB_DEV void row_allreduce_n(T (&v)[K], T*, int) {
+template <class T, int K> UKFB_DEV void row_allreduce_n(T (&v)[K]) {
 #pragma unroll
     for (int c = 0; c < K; ++c) v[c] = row_allreduce(v[c]);
 }
@@ -176,7 +178,7 @@ template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layo
 // broadcasts (lane c's A[c][k] for the trailing update, lane k's pivot); column k is published UNSCALED
 // (v_l = a_l[k], pivot included) with one LDS write for the consumers.  L[c][k] = Lc[k*LS+c]*rs_k
 // for c >= k (entries above the diagonal are garbage and must be masked by the consumer).
-// Returns this lane's rs_l (lane l < D); ok = all pivots > 0.  `dum`: offset of the store sink.
+// Returns this lane's rs_l (lane l < D); ok = all pivots > 0.
 // ---------------------------------------------------------------------------------------------
 // scheduling fence: keeps the machine scheduler from hoisting the next phase's loads / ALU work
 // across this point (it otherwise trades ~2x the registers for ILP and ends up spilling)
@@ -187,7 +189,7 @@ UKFB_DEV void keep(float& x) { asm volatile("" : "+v"(x)); }
 UKFB_DEV void keep(double& x) { asm volatile("" : "+v"(x)); }
 
 // KS < D factorises the first KS columns only (consumers that need no more; pivots KS.. are then not checked).
-template <class T, int D, int LS, int KS = D> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, int dum, bool& ok) {
+template <class T, int D, int LS, int KS = D> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, bool& ok) {
     bool good = true;
     // lanes >= D carry a copy of row D-1 (load_row clamps) and store the same values to the same addresses
     const int lw = (l < D) ? l : (D - 1);
@@ -273,28 +275,24 @@ template <class T> UKFB_DEV void process_fast(OrientM<T>*, T (&x)[14], const Pro
     }
 }
 
-// sigma pair mu [+] (+col), mu [+] (-col).  need_q = false skips the SO(3) part (measurement models
-// that do not read the orientation).
+// sigma pair mu [+] (+col), mu [+] (-col): one exp serves both points, exp(-v) = conj(exp(v))
 template <class T, class M>
-UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], bool need_q, T (&xp)[M::S], T (&xm)[M::S]) {
+UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], T (&xp)[M::S], T (&xm)[M::S]) {
     constexpr int Q = MT<M>::Q, RT = MT<M>::RT, S = M::S;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         if (s < Q) { xp[s] = mu[s] + col[s]; xm[s] = mu[s] - col[s]; }
         else if (s >= Q + 4) { xp[s] = mu[s] + col[s - 1]; xm[s] = mu[s] - col[s - 1]; }
-        else { xp[s] = mu[s]; xm[s] = mu[s]; }
     }
-    if (need_q) {   // wave-uniform
-        const T q[4] = {mu[Q], mu[Q + 1], mu[Q + 2], mu[Q + 3]};
-        const T v[3] = {col[RT], col[RT + 1], col[RT + 2]};
-        T ep[4], rp[4], rm[4];
-        so3_exp_fast(v, T(1), ep);
-        const T em[4] = {-ep[0], -ep[1], -ep[2], ep[3]};
-        quat_mul(q, ep, rp);
-        quat_mul(q, em, rm);
+    const T q[4] = {mu[Q], mu[Q + 1], mu[Q + 2], mu[Q + 3]};
+    const T v[3] = {col[RT], col[RT + 1], col[RT + 2]};
+    T ep[4], rp[4], rm[4];
+    so3_exp_fast(v, T(1), ep);
+    const T em[4] = {-ep[0], -ep[1], -ep[2], ep[3]};
+    quat_mul(q, ep, rp);
+    quat_mul(q, em, rm);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { xp[Q + k] = rp[k]; xm[Q + k] = rm[k]; }
-    }
+    for (int k = 0; k < 4; ++k) { xp[Q + k] = rp[k]; xm[Q + k] = rm[k]; }
 }
 
 // One entry of the shaped process noise R without exec-masked regions (cf. process_noise_entry).
@@ -358,7 +356,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     T* ZQ = base + LY::ZQ;
     T* WK = base + LY::WK;
     T* DUMP = base + LY::DUM;
-    T* RED = nullptr;
     const bool has_pair = l < D;       // lane owns the sigma pair of column l
     const bool has_ctr = l == D;       // lane owns the centre point
 
@@ -485,14 +482,12 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 {
                     T arow[D];
                     load_row<T, D>(PKS, l, arow);
-                    rs = chol16<T, D, LS>(arow, Lc, l, LY::DUM - LY::LC, ok);
+                    rs = chol16<T, D, LS>(arow, Lc, l, ok);
                     wsync();
                 }
                 T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
-                sigma_pair<T, M>(mu_r, col, true, xp, xm);
-#pragma unroll
-                for (int s = 0; s < S; ++s) ref[s] = mu_r[s];
+                sigma_pair<T, M>(mu_r, col, xp, xm);
             }
             const bool pc = do_p && ok;            // this filter's predict will be committed
             sfence();
@@ -608,7 +603,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     T m2 = T(0);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) mr[k] = fma(wm, rm[k], wp * rp[k]);
-                    row_allreduce_n<T, 3>(mr, RED, l);
+                    row_allreduce_n<T, 3>(mr);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         mr[k] *= (T(1) / T(N));
@@ -808,7 +803,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     // Only the first ZCOLS columns of the factor move the measurement.  An indefinite Sigma whose
                     // first ZCOLS pivots are positive is caught by the complete factorisation of Sigma' below
                     // (Sigma' <= Sigma), with the same status bit.
-                    rs = chol16<T, D, LS, MT<M>::ZCOLS>(arow, Lc, l, LY::DUM - LY::LC, okg);
+                    rs = chol16<T, D, LS, MT<M>::ZCOLS>(arow, Lc, l, okg);
                     wsync();
                 }
                 T zp[4], zm[4], z0[4];
@@ -840,7 +835,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         T m2 = T(0);
 #pragma unroll
                         for (int k = 0; k < 3; ++k) mr[k] = has_pair ? (rp[k] + rm[k]) : T(0);
-                        row_allreduce_n<T, 3>(mr, RED, l);
+                        row_allreduce_n<T, 3>(mr);
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             mr[k] = (mr[k] + r0v[k]) * (T(1) / T(N));
@@ -862,7 +857,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     T zr[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) zr[k] = has_pair ? ((zp[k] - z0[k]) + (zm[k] - z0[k])) : T(0);
-                    row_allreduce_n<T, 3>(zr, RED, l);
+                    row_allreduce_n<T, 3>(zr);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) zr[k] = z0[k] + zr[k] * (T(1) / T(N));
 #pragma unroll
@@ -908,7 +903,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
                         for (int c = 0; c <= r; ++c)
                             u6[r * (r + 1) / 2 + c] = has_pair ? fma(dzp[r], dzp[c], dzm[r] * dzm[c]) : T(0);
-                    row_allreduce_n<T, 6>(u6, RED, l);
+                    row_allreduce_n<T, 6>(u6);
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -988,7 +983,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     srow2[b] = arow2[b];
                     d0[b] = row_bcast<b>(del);
                 });
-                rs2 = chol16<T, D, LS>(arow2, Lc, l, LY::DUM - LY::LC, ok2);
+                rs2 = chol16<T, D, LS>(arow2, Lc, l, ok2);
                 wsync();
             }
             sfence();
@@ -1016,7 +1011,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c <= r; ++c) rr[r * (r + 1) / 2 + c] = has_pair ? fma(rp[r], rp[c], rm[r] * rm[c]) : T(0);
-            row_allreduce_n<T, 6>(rr, RED, l);
+            row_allreduce_n<T, 6>(rr);
 #pragma unroll
             for (int k = 0; k < 6; ++k) rr[k] *= T(0.5);
             // cross terms of row l with the three rotation columns.  Columns past the rotation block have a zero

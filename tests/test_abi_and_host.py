@@ -26,6 +26,25 @@ def test_library_exports_every_declared_symbol(spe):
     assert missing == []
 
 
+def test_header_is_plain_c_and_links_from_c(spe, tmp_path):
+    """The boundary is a C ABI: the header must compile as strict C99 and a C program must link the library
+    (without a GPU ukfb_create reports an error code instead of crashing)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include <stdio.h>\n#include "ukf_batch.h"\n'
+                   'int main(void) { ukfb_engine* e = 0;\n'
+                   '  int rc = ukfb_create(&e, UKFB_MODEL_POSE, UKFB_F64, 4, 0, 0);\n'
+                   '  printf("%d %s\\n", rc, rc == UKFB_OK ? "ok" : ukfb_last_error());\n'
+                   '  if (rc == UKFB_OK) ukfb_destroy(e);\n  return 0; }\n')
+    exe = tmp_path / "c_abi"
+    lib = os.path.join(root, "slam-pose_estimation_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe), "-L", lib, "-lukf_batch", "-Wl,-rpath," + lib])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() != ""
+
+
 def test_default_config_matches_reference_defaults(spe):
     import ctypes as C
     lib = spe.load_library()

@@ -279,3 +279,47 @@ def test_orientation_predict_and_velocity_update_against_40_digits(spe, oracle):
             return qrot(qi, x[4:7])[0]
         mu2, cu2 = mp_update(ORIENT, to_mp(m_p[i]), to_mp(0.5 * (c_p[i] + c_p[i].T)), to_mp(z[i]), to_mp(Q[i]), h, tol)
         assert max_abs(to_np(mu2), m_u[i]) < 1e-13 and max_abs(to_np(cu2), c_u[i]) < 1e-13
+
+
+def mp_update_so3(man, mu, Sig, zq, Q, h, tol):
+    """ukfom::ukf::update with an SO(3)-valued measurement (iterated mean of Z, deltas through log)."""
+    D = dof(man)
+    so3 = [("so3", 0, 0, 3)]
+    X = sigma_points(man, mu, Sig)
+    Z = [h(x) for x in X]
+    zbar = manifold_mean(so3, Z, tol)
+    Sm = mp.matrix(3, 3)
+    Cxz = mp.matrix(D, 3)
+    for x, zz in zip(X, Z):
+        dz = boxminus(so3, zz, zbar)
+        dx = boxminus(man, x, mu)
+        for a in range(3):
+            for b in range(3):
+                Sm[a, b] += dz[a] * dz[b] / 2
+        for a in range(D):
+            for b in range(3):
+                Cxz[a, b] += dx[a] * dz[b] / 2
+    Sm = Sm + Q
+    K = Cxz * (Sm ** -1)
+    delta = K * mp.matrix(boxminus(so3, zq, zbar))
+    Sig2 = Sig - K * Sm * K.T
+    Xn = sigma_points(man, mu, Sig2, [delta[k] for k in range(D)])
+    return Xn[0], half_cov(man, Xn, Xn[0])
+
+
+def test_pose_orientation_update_on_so3_against_40_digits(spe, oracle):
+    """integrateMeasurement(OrientationMeasurement): z = SO3::exp(mu) (PoseUKF.cpp:133-138), h = orientation
+    (PoseUKF.cpp:28-33); the measurement lives on SO(3)."""
+    n = 3
+    rng = np.random.default_rng(5)
+    mu, cov = spe.synth.pose_initial(n)
+    Q = np.stack([np.eye(3) * 0.01] * n)
+    tol = mp.mpf(float(oracle.default_config().mean_tol))
+    # axis-angle measurements near the state's orientation
+    z = np.stack([oracle.so3_log(mu[i, 3:7]) + rng.uniform(-0.05, 0.05, 3) for i in range(n)])
+    m_u, c_u, st = oracle.pose_update(mu, cov, spe.MEAS_ORIENT_SO3, z, Q)
+    assert (st == 0).all()
+    for i in range(n):
+        zq = so3_exp(to_mp(z[i]))
+        mu2, cu2 = mp_update_so3(POSE, to_mp(mu[i]), to_mp(cov[i]), zq, to_mp(Q[i]), lambda x: x[3:7], tol)
+        assert max_abs(to_np(mu2), m_u[i]) < 1e-13 and max_abs(to_np(cu2), c_u[i]) < 1e-13

@@ -123,7 +123,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
     dist = None
-    if world > 1:
+    # UKFB_BENCH_FORCE_DIST=1 under torchrun: rehearsal of the N>1 plumbing (RCCL init, barrier, all_reduce,
+    # gather) with a single rank on a one-GPU box
+    if world > 1 or ("RANK" in os.environ and os.environ.get("UKFB_BENCH_FORCE_DIST")):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dev_index = local_rank % max(1, torch.cuda.device_count())

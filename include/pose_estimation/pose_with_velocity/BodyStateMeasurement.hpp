@@ -14,47 +14,49 @@ namespace pose_estimation
 
 struct BodyStateMeasurement
 {
-    /** :14-26 -- fields copied as they are; block-diagonal covariance at (0,0) (3,3) (6,6) (9,9). */
-    static void fromRigidBodyState(const base::samples::RigidBodyState &body_state, PoseWithVelocity &filter_state, PoseWithVelocityCovariance &filter_state_cov)
-    {
-        filter_state.position = body_state.position;
-        filter_state.orientation = body_state.orientation;
-        filter_state.velocity = body_state.velocity;
-        filter_state.angular_velocity = body_state.angular_velocity;
+    /** tangent offset of the four 3x3 covariance blocks: position, orientation, velocity, angular velocity */
+    static int blockOffset(int field) { return 3 * field; }
 
-        filter_state_cov = PoseWithVelocityCovariance::Zero();
-        filter_state_cov.setBlock<3, 3>(0, 0, body_state.cov_position);
-        filter_state_cov.setBlock<3, 3>(3, 3, body_state.cov_orientation);
-        filter_state_cov.setBlock<3, 3>(6, 6, body_state.cov_velocity);
-        filter_state_cov.setBlock<3, 3>(9, 9, body_state.cov_angular_velocity);
+    /** one 49-double record of the engine's batched adapters (ukf_batch.h): p(3) q(4, xyzw) v(3) w(3) and the
+     *  four 3x3 blocks, row-major */
+    static void toRecord(const base::samples::RigidBodyState &rbs, double* rec)
+    {
+        for (int k = 0; k < 3; ++k) { rec[k] = rbs.position[k]; rec[7 + k] = rbs.velocity[k]; rec[10 + k] = rbs.angular_velocity[k]; }
+        for (int k = 0; k < 4; ++k) rec[3 + k] = rbs.orientation.coeffs()[k];
+        for (int k = 0; k < 9; ++k) { rec[13 + k] = rbs.cov_position[k]; rec[22 + k] = rbs.cov_orientation[k]; rec[31 + k] = rbs.cov_velocity[k]; rec[40 + k] = rbs.cov_angular_velocity[k]; }
+    }
+    static void fromRecord(const double* rec, base::samples::RigidBodyState &rbs)
+    {
+        for (int k = 0; k < 3; ++k) { rbs.position[k] = rec[k]; rbs.velocity[k] = rec[7 + k]; rbs.angular_velocity[k] = rec[10 + k]; }
+        for (int k = 0; k < 4; ++k) rbs.orientation.coeffs()[k] = rec[3 + k];
+        for (int k = 0; k < 9; ++k) { rbs.cov_position[k] = rec[13 + k]; rbs.cov_orientation[k] = rec[22 + k]; rbs.cov_velocity[k] = rec[31 + k]; rbs.cov_angular_velocity[k] = rec[40 + k]; }
     }
 
-    /** :28-39 -- velocity is rotated into the navigation frame (:32). */
-    static void toRigidBodyState(const PoseWithVelocity &filter_state, const PoseWithVelocityCovariance &filter_state_cov, base::samples::RigidBodyState &body_state)
+    /** reference :14-26.  Same statements as the device kernel import_body_states_kernel (ukf_batch.hip): the
+     *  sample's fields become the state, its four covariances the diagonal blocks, everything else zero. */
+    static void fromRigidBodyState(const base::samples::RigidBodyState &sample, PoseWithVelocity &x, PoseWithVelocityCovariance &P)
     {
-        body_state.position = filter_state.position;
-        body_state.orientation = filter_state.orientation;
-        body_state.velocity = body_state.orientation * filter_state.velocity;
-        body_state.angular_velocity = filter_state.angular_velocity;
-
-        body_state.cov_position = filter_state_cov.block<3, 3>(0, 0);
-        body_state.cov_orientation = filter_state_cov.block<3, 3>(3, 3);
-        body_state.cov_velocity = filter_state_cov.block<3, 3>(6, 6);
-        body_state.cov_angular_velocity = filter_state_cov.block<3, 3>(9, 9);
+        double rec[49];
+        toRecord(sample, rec);
+        for (int k = 0; k < 3; ++k) { x.position[k] = rec[k]; x.velocity[k] = rec[7 + k]; x.angular_velocity[k] = rec[10 + k]; }
+        for (int k = 0; k < 4; ++k) x.orientation.coeffs()[k] = rec[3 + k];
+        P = PoseWithVelocityCovariance::Zero();
+        for (int f = 0; f < 4; ++f)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) P(blockOffset(f) + i, blockOffset(f) + j) = rec[13 + 9 * f + 3 * i + j];
     }
 
-    /** one 49-double record of the engine's batched adapters <-> RigidBodyState */
-    static void toRecord(const base::samples::RigidBodyState &b, double* r)
+    /** reference :28-39.  The velocity leaves in the navigation frame: rotated by the orientation (:32). */
+    static void toRigidBodyState(const PoseWithVelocity &x, const PoseWithVelocityCovariance &P, base::samples::RigidBodyState &sample)
     {
-        for (int k = 0; k < 3; ++k) { r[k] = b.position[k]; r[7 + k] = b.velocity[k]; r[10 + k] = b.angular_velocity[k]; }
-        for (int k = 0; k < 4; ++k) r[3 + k] = b.orientation.coeffs()[k];
-        for (int k = 0; k < 9; ++k) { r[13 + k] = b.cov_position[k]; r[22 + k] = b.cov_orientation[k]; r[31 + k] = b.cov_velocity[k]; r[40 + k] = b.cov_angular_velocity[k]; }
-    }
-    static void fromRecord(const double* r, base::samples::RigidBodyState &b)
-    {
-        for (int k = 0; k < 3; ++k) { b.position[k] = r[k]; b.velocity[k] = r[7 + k]; b.angular_velocity[k] = r[10 + k]; }
-        for (int k = 0; k < 4; ++k) b.orientation.coeffs()[k] = r[3 + k];
-        for (int k = 0; k < 9; ++k) { b.cov_position[k] = r[13 + k]; b.cov_orientation[k] = r[22 + k]; b.cov_velocity[k] = r[31 + k]; b.cov_angular_velocity[k] = r[40 + k]; }
+        double rec[49];
+        const Vector3d v_nav = x.orientation * x.velocity;
+        for (int k = 0; k < 3; ++k) { rec[k] = x.position[k]; rec[7 + k] = v_nav[k]; rec[10 + k] = x.angular_velocity[k]; }
+        for (int k = 0; k < 4; ++k) rec[3 + k] = x.orientation.coeffs()[k];
+        for (int f = 0; f < 4; ++f)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) rec[13 + 9 * f + 3 * i + j] = P(blockOffset(f) + i, blockOffset(f) + j);
+        fromRecord(rec, sample);
     }
 };
 

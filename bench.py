@@ -200,6 +200,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed pre-roll: the FIRST burst of queued launches in a process is reported complete ~50 ms late by the
+    # runtime in about one process out of three (GPU timestamps show the kernels back to back; later bursts
+    # never, tools/sync_latency.py and DESIGN.md section 5).  A short burst (up to 64 launches)
+    # absorbs that one-time event before the W warm-up steps and the K timed steps.
+    for k in range(min(args.steps, 64)):
+        step(k)
+    fence()
     for k in range(args.warmup):
         step(k)
     fence()

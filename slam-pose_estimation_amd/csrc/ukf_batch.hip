@@ -368,9 +368,10 @@ int ukfb_destroy(ukfb_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->in_a, e->in_b, e->z_stage, e->Q_stage,
-                    e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word};
+                    e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->ev_acc};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (e->ev_host) (void)hipHostFree(e->ev_host);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -805,53 +806,83 @@ int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter,
     for (int64_t i = 0; i < n_events; ++i)
         if (filter[i] < 0 || filter[i] >= e->cap || ts_us[i] < 0)
             return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
-    // per filter: stable time order; the rank of a sample within its filter is its round
+    // per filter: stable time order; the rank of a sample within its filter is its round.  Filter ids are dense,
+    // so this is a counting sort by filter (arrival order kept) followed by an insertion sort by time inside each
+    // (short) bucket: linear in the number of events, where a comparison sort of the whole stream was 2/3 of the call
     std::vector<int64_t> order(static_cast<size_t>(n_events), 0);
-    for (int64_t i = 0; i < n_events; ++i) order[size_t(i)] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-        if (filter[a] != filter[b]) return filter[a] < filter[b];
-        return ts_us[a] < ts_us[b];
-    });
     std::vector<int64_t> round_of(static_cast<size_t>(n_events), 0);
     int64_t nrounds = 0;
-    for (int64_t k = 0, run = 0; k < n_events; ++k) {
-        run = (k > 0 && filter[order[size_t(k)]] == filter[order[size_t(k - 1)]]) ? run + 1 : 0;
-        round_of[size_t(k)] = run;
-        nrounds = std::max(nrounds, run + 1);
+    {
+        std::vector<int64_t> first(static_cast<size_t>(e->cap) + 1, 0);
+        for (int64_t i = 0; i < n_events; ++i) ++first[size_t(filter[i]) + 1];
+        for (int64_t f = 0; f < e->cap; ++f) first[size_t(f) + 1] += first[size_t(f)];
+        {
+            std::vector<int64_t> fill(first.begin(), first.end() - 1);
+            for (int64_t i = 0; i < n_events; ++i) order[size_t(fill[size_t(filter[i])]++)] = i;
+        }
+        for (int64_t f = 0; f < e->cap; ++f) {
+            const int64_t b0 = first[size_t(f)], b1 = first[size_t(f) + 1];
+            for (int64_t k = b0 + 1; k < b1; ++k) {   // stable insertion sort by timestamp
+                const int64_t cur = order[size_t(k)];
+                int64_t j = k;
+                while (j > b0 && ts_us[order[size_t(j - 1)]] > ts_us[cur]) {
+                    order[size_t(j)] = order[size_t(j - 1)];
+                    --j;
+                }
+                order[size_t(j)] = cur;
+            }
+            for (int64_t k = b0; k < b1; ++k) round_of[size_t(k)] = k - b0;
+            nrounds = std::max(nrounds, b1 - b0);
+        }
     }
-    // samples grouped by round (counting sort), packed for one upload
+    // samples grouped by round (counting sort), packed in engine precision into ONE pinned arena and uploaded with
+    // one copy; arena and device twin are kept by the engine and only ever grow
     std::vector<int64_t> start(static_cast<size_t>(nrounds) + 1, 0);
     for (int64_t k = 0; k < n_events; ++k) ++start[size_t(round_of[size_t(k)]) + 1];
     for (int64_t r = 0; r < nrounds; ++r) start[size_t(r) + 1] += start[size_t(r)];
     const size_t ne = static_cast<size_t>(n_events);
-    std::vector<int64_t> pos(start.begin(), start.end() - 1);
-    std::vector<int64_t> pf(ne, 0), pt(ne, 0);
-    std::vector<int32_t> pm(ne, 0);
-    std::vector<double> pz(ne * 3, 0.0), pq(ne * 9, 0.0);
-    for (int64_t k = 0; k < n_events; ++k) {
-        const int64_t src = order[size_t(k)], dst = pos[size_t(round_of[size_t(k)])]++;
-        pf[size_t(dst)] = filter[src];
-        pt[size_t(dst)] = ts_us[src];
-        pm[size_t(dst)] = meas_model[src];
-        std::memcpy(&pz[size_t(dst) * 3], z + src * 3, 3 * sizeof(double));
-        std::memcpy(&pq[size_t(dst) * 9], Q + src * 9, 9 * sizeof(double));
+    const size_t off_f = 0, off_t = off_f + ne * sizeof(int64_t), off_z = off_t + ne * sizeof(int64_t),
+                 off_q = off_z + ne * 3 * e->tsize, off_m = off_q + ne * 9 * e->tsize,
+                 bytes = ((off_m + ne * sizeof(int32_t) + 255) / 256) * 256;
+    if (bytes > e->ev_bytes) {
+        if (e->ev_host) HIP_TRY(hipHostFree(e->ev_host));
+        if (e->ev_dev) HIP_TRY(hipFree(e->ev_dev));
+        e->ev_host = e->ev_dev = nullptr;
+        e->ev_bytes = 0;
+        HIP_TRY(hipHostMalloc(&e->ev_host, bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&e->ev_dev, bytes));
+        e->ev_bytes = bytes;
     }
-    int64_t *d_f = nullptr, *d_t = nullptr;
-    int32_t* d_m = nullptr;
-    void *d_z = nullptr, *d_q = nullptr;
-    uint32_t* d_acc = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_f), size_t(n_events) * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n_events) * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_m), size_t(n_events) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&d_z, size_t(n_events) * 3 * e->tsize));
-    HIP_TRY(hipMalloc(&d_q, size_t(n_events) * 9 * e->tsize));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_acc), size_t(e->cap) * sizeof(uint32_t)));
-    int rc = upload_raw(e, d_f, pf.data(), pf.size());
-    if (!rc) rc = upload_raw(e, d_t, pt.data(), pt.size());
-    if (!rc) rc = upload_raw(e, d_m, pm.data(), pm.size());
-    if (!rc) rc = upload(e, d_z, 0, pz.data(), pz.size());
-    if (!rc) rc = upload(e, d_q, 0, pq.data(), pq.size());
-    if (rc) return rc;
+    if (!e->ev_acc) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ev_acc), size_t(e->cap) * sizeof(uint32_t)));
+    {
+        char* hb = static_cast<char*>(e->ev_host);
+        int64_t* pf = reinterpret_cast<int64_t*>(hb + off_f);
+        int64_t* pt = reinterpret_cast<int64_t*>(hb + off_t);
+        int32_t* pm = reinterpret_cast<int32_t*>(hb + off_m);
+        std::vector<int64_t> pos(start.begin(), start.end() - 1);
+        for (int64_t k = 0; k < n_events; ++k) {
+            const int64_t src = order[size_t(k)], dst = pos[size_t(round_of[size_t(k)])]++;
+            pf[dst] = filter[src];
+            pt[dst] = ts_us[src];
+            pm[dst] = meas_model[src];
+            if (e->prec == UKFB_F64) {
+                std::memcpy(reinterpret_cast<double*>(hb + off_z) + dst * 3, z + src * 3, 3 * sizeof(double));
+                std::memcpy(reinterpret_cast<double*>(hb + off_q) + dst * 9, Q + src * 9, 9 * sizeof(double));
+            } else {
+                convert(z + src * 3, reinterpret_cast<float*>(hb + off_z) + dst * 3, 3);
+                convert(Q + src * 9, reinterpret_cast<float*>(hb + off_q) + dst * 9, 9);
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(e->ev_dev, e->ev_host, bytes, hipMemcpyHostToDevice, e->stream));
+    char* db = static_cast<char*>(e->ev_dev);
+    const int64_t* d_f = reinterpret_cast<const int64_t*>(db + off_f);
+    const int64_t* d_t = reinterpret_cast<const int64_t*>(db + off_t);
+    const int32_t* d_m = reinterpret_cast<const int32_t*>(db + off_m);
+    const void* d_z = db + off_z;
+    const void* d_q = db + off_q;
+    uint32_t* d_acc = e->ev_acc;
+    int rc = UKFB_OK;
     HIP_TRY(hipMemsetAsync(d_acc, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
     const int cap_blocks = int((e->cap + 255) / 256);
     for (int64_t r = 0; r < nrounds; ++r) {
@@ -873,9 +904,7 @@ int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter,
                            e->cap);
     }
     HIP_TRY(hipMemcpyAsync(e->status, d_acc, size_t(e->cap) * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    void* frees[] = {d_f, d_t, d_m, d_z, d_q, d_acc};
-    for (void* b : frees) HIP_TRY(hipFree(b));
+    HIP_TRY(hipStreamSynchronize(e->stream));   // the pinned arena may be reused by the next call
     if (rounds) *rounds = nrounds;
     if (status_or) return ukfb_get_status_summary(e, status_or);
     return UKFB_OK;

@@ -48,6 +48,11 @@ struct ukfb_engine {
     double* dt_stage = nullptr;
     int64_t* ts_stage = nullptr;
     uint32_t* reduce_word = nullptr;  // status OR-reduction target
+    // ukfb_process_events: pinned host arena and its device twin (grow-only), status accumulator [cap]
+    void* ev_host = nullptr;
+    void* ev_dev = nullptr;
+    size_t ev_bytes = 0;
+    uint32_t* ev_acc = nullptr;
 
     // last launch (for bench.py / profiles)
     std::string last_kernel;

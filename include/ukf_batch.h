@@ -217,6 +217,12 @@ int ukfb_cycle_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev, const in
  * of launches. */
 int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter, const int64_t* ts_us,
                         const int32_t* meas_model, const double* z, const double* Q, uint32_t* status_or, int64_t* rounds);
+/* Same stream already resident in HBM (z, Q in the engine's precision): ordering (two stable radix sorts:
+ * timestamp, then filter index), ranking and the per-round scatter all run on the device; the host only
+ * learns the number of rounds.  The host-pointer variant above uploads the five arrays and calls this. */
+int ukfb_process_events_dev(ukfb_engine* e, int64_t n_events, const int64_t* filter_dev, const int64_t* ts_us_dev,
+                            const int32_t* meas_model_dev, const void* z_dev, const void* Q_dev, uint32_t* status_or,
+                            int64_t* rounds);
 
 /* ---- measurement of the engine itself ---------------------------------------------------- */
 /* name, dynamic LDS bytes per workgroup, filters per workgroup and grid size of the kernel the

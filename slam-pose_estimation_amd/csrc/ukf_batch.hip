@@ -11,6 +11,8 @@
 #include <limits>
 #include <new>
 
+#include <hipcub/hipcub.hpp>
+
 #include "ukf_engine.hpp"
 
 namespace {
@@ -228,18 +230,47 @@ template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t
     return UKFB_OK;
 }
 
-// event queue helpers: scatter one round of samples into the dense per-filter staging arrays
-template <class T>
-__global__ void scatter_events_kernel(const int64_t* filt, const int64_t* ts, const int32_t* meas, const T* z, const T* Q,
-                                      int64_t n, int64_t* ts_dense, int32_t* meas_dense, T* z_dense, T* Q_dense) {
-    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    if (i >= n) return;
-    const int64_t f = filt[i];
+// ---- device-side ordering of an event stream ------------------------------------------------------------
+__global__ void events_init_kernel(const int64_t* filt, const int64_t* ts, int64_t n, int64_t cap, uint32_t* idx,
+                                   int64_t* key_t, uint32_t* flags) {
+    const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    idx[k] = uint32_t(k);
+    key_t[k] = ts[k];
+    if (filt[k] < 0 || filt[k] >= cap || ts[k] < 0) atomicOr(&flags[0], 1u);
+}
+__global__ void events_filter_keys_kernel(const int64_t* filt, const uint32_t* idx, int64_t n, int64_t cap, uint32_t* key_f) {
+    const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const int64_t f = filt[idx[k]];
+    key_f[k] = uint32_t((f < 0 || f >= cap) ? 0 : f);
+}
+__global__ void events_heads_kernel(const uint32_t* key_f_sorted, int64_t n, uint32_t* head) {
+    const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    head[k] = (k == 0 || key_f_sorted[k] != key_f_sorted[k - 1]) ? uint32_t(k) : 0u;
+}
+__global__ void events_rank_kernel(const uint32_t* start, int64_t n, uint32_t* rank, uint32_t* flags) {
+    const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t r = uint32_t(k) - start[k];
+    rank[k] = r;
+    atomicMax(&flags[1], r);
+}
+// round r: the r-th sample (in time order) of every filter goes to the dense per-filter staging arrays
+template <class S, class T>
+__global__ void events_scatter_round_kernel(const int64_t* filt, const int64_t* ts, const int32_t* meas, const S* z, const S* Q,
+                                            const uint32_t* order, const uint32_t* rank, uint32_t round, int64_t n,
+                                            int64_t* ts_dense, int32_t* meas_dense, T* z_dense, T* Q_dense) {
+    const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (k >= n || rank[k] != round) return;
+    const int64_t i = order[k], f = filt[i];
     ts_dense[f] = ts[i];
     meas_dense[f] = meas[i];
-    for (int k = 0; k < 3; ++k) z_dense[f * 3 + k] = z[i * 3 + k];
-    for (int k = 0; k < 9; ++k) Q_dense[f * 9 + k] = Q[i * 9 + k];
+    for (int c = 0; c < 3; ++c) z_dense[f * 3 + c] = T(z[i * 3 + c]);
+    for (int c = 0; c < 9; ++c) Q_dense[f * 9 + c] = T(Q[i * 9 + c]);
 }
+
 // OR the status words of the round into the accumulator; filters without a sample in this round contribute
 // nothing (their word is the INACTIVE marker only)
 __global__ void accumulate_status_kernel(const uint32_t* st, const int64_t* ts_dense, uint32_t* acc, int64_t n) {
@@ -371,7 +402,6 @@ int ukfb_destroy(ukfb_engine* e) {
                     e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->ev_acc};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    if (e->ev_host) (void)hipHostFree(e->ev_host);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -795,119 +825,164 @@ int ukfb_cycle_timestamps(ukfb_engine* e, const int64_t* ts_us, const int32_t* m
 }
 
 // ---- time-ordered asynchronous measurement stream -------------------------------------------------
+}  // extern "C"
+
+// Device pipeline shared by both entry points.  Events are in device memory (z, Q in precision S); everything
+// else lives in the engine's grow-only workspace `ev_dev`.  Ordering: radix sort by timestamp, then stable radix
+// sort by filter index (hipCUB) = per-filter time order with arrival order for equal stamps; the rank of a sample
+// inside its filter's run is its round.
+namespace {
+struct Carver {   // bump allocator over the workspace (256-byte aligned pieces)
+    char* base;
+    size_t used = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    template <class P> P* take(size_t count) {
+        P* p = base ? reinterpret_cast<P*>(base + used) : nullptr;
+        used += (count * sizeof(P) + 255) / 256 * 256;
+        return p;
+    }
+};
+
+template <class S>
+int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const int64_t* d_t, const int32_t* d_m, const S* d_z,
+                          const S* d_q, size_t ws_offset, uint32_t* status_or, int64_t* rounds) {
+    const int bits_f = std::max(1, int(std::ceil(std::log2(double(std::max<int64_t>(e->cap, 2))))));
+    size_t tmp_sort_t = 0, tmp_sort_f = 0, tmp_scan = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort_t, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr),
+                                               static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, 64,
+                                               e->stream));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort_f, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                               static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, bits_f,
+                                               e->stream));
+    HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                              hipcub::Max(), int(n), e->stream));
+    const size_t tmp_bytes = std::max(tmp_sort_t, std::max(tmp_sort_f, tmp_scan));
+    Carver c(static_cast<char*>(e->ev_dev) + ws_offset);
+    const size_t ne = size_t(n);
+    uint32_t* idx_a = c.take<uint32_t>(ne);
+    uint32_t* idx_b = c.take<uint32_t>(ne);
+    uint32_t* idx_c = c.take<uint32_t>(ne);
+    int64_t* key_t_a = c.take<int64_t>(ne);
+    int64_t* key_t_b = c.take<int64_t>(ne);
+    uint32_t* key_f_a = c.take<uint32_t>(ne);
+    uint32_t* key_f_b = c.take<uint32_t>(ne);
+    uint32_t* head = c.take<uint32_t>(ne);
+    uint32_t* start = c.take<uint32_t>(ne);
+    uint32_t* rank = c.take<uint32_t>(ne);
+    uint32_t* flags = c.take<uint32_t>(2);
+    char* tmp = c.take<char>(tmp_bytes);
+    if (ws_offset + c.used > e->ev_bytes) return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events: workspace too small (internal)");
+    if (!e->ev_acc) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ev_acc), size_t(e->cap) * sizeof(uint32_t)));
+
+    const int blocks = int((n + 255) / 256), cap_blocks = int((e->cap + 255) / 256);
+    HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), e->stream));
+    hipLaunchKernelGGL(events_init_kernel, dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, n, e->cap, idx_a, key_t_a, flags);
+    size_t tb = tmp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_t_a, key_t_b, idx_a, idx_b, int(n), 0, 64, e->stream));
+    hipLaunchKernelGGL(events_filter_keys_kernel, dim3(blocks), dim3(256), 0, e->stream, d_f, idx_b, n, e->cap, key_f_a);
+    tb = tmp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_f_a, key_f_b, idx_b, idx_c, int(n), 0, bits_f, e->stream));
+    hipLaunchKernelGGL(events_heads_kernel, dim3(blocks), dim3(256), 0, e->stream, key_f_b, n, head);
+    tb = tmp_bytes;
+    HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, start, hipcub::Max(), int(n), e->stream));
+    hipLaunchKernelGGL(events_rank_kernel, dim3(blocks), dim3(256), 0, e->stream, start, n, rank, flags);
+    uint32_t hflags[2] = {0, 0};
+    int rc = download_raw(e, flags, hflags, 2);
+    if (rc) return rc;
+    if (hflags[0]) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
+    const int64_t nrounds = int64_t(hflags[1]) + 1;
+
+    HIP_TRY(hipMemsetAsync(e->ev_acc, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
+    for (int64_t r = 0; r < nrounds; ++r) {
+        HIP_TRY(hipMemsetAsync(e->ts_stage, 0xFF, size_t(e->cap) * sizeof(int64_t), e->stream));     // -1: no sample
+        HIP_TRY(hipMemsetAsync(e->meas_stage, 0xFF, size_t(e->cap) * sizeof(int32_t), e->stream));   // -1: no measurement
+        if (e->prec == UKFB_F64)
+            hipLaunchKernelGGL((events_scatter_round_kernel<S, double>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z,
+                               d_q, idx_c, rank, uint32_t(r), n, e->ts_stage, e->meas_stage, static_cast<double*>(e->z_stage),
+                               static_cast<double*>(e->Q_stage));
+        else
+            hipLaunchKernelGGL((events_scatter_round_kernel<S, float>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z,
+                               d_q, idx_c, rank, uint32_t(r), n, e->ts_stage, e->meas_stage, static_cast<float*>(e->z_stage),
+                               static_cast<float*>(e->Q_stage));
+        rc = ukfb_cycle_timestamps_dev(e, e->ts_stage, e->meas_stage, e->z_stage, e->Q_stage);
+        if (rc) return rc;
+        hipLaunchKernelGGL(accumulate_status_kernel, dim3(cap_blocks), dim3(256), 0, e->stream, e->status, e->ts_stage, e->ev_acc,
+                           e->cap);
+    }
+    HIP_TRY(hipMemcpyAsync(e->status, e->ev_acc, size_t(e->cap) * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+    if (rounds) *rounds = nrounds;
+    if (status_or) return ukfb_get_status_summary(e, status_or);
+    return UKFB_OK;
+}
+
+// bytes of workspace process_events_device needs for n events (an upper bound that does not depend on hipCUB's
+// temporary-storage query: 4x the key/value arrays covers rocPRIM's double buffers)
+size_t events_workspace_bytes(int64_t n) {
+    const size_t ne = size_t(n);
+    return (3 * 4 + 2 * 8 + 2 * 4 + 3 * 4) * ne + 12 * 256 + (size_t(64) << 20) / 4 + 24 * ne;
+}
+
+int ensure_events_arena(ukfb_engine* e, size_t bytes) {
+    if (bytes <= e->ev_bytes) return UKFB_OK;
+    if (e->ev_dev) HIP_TRY(hipFree(e->ev_dev));
+    e->ev_dev = nullptr;
+    e->ev_bytes = 0;
+    HIP_TRY(hipMalloc(&e->ev_dev, bytes));
+    e->ev_bytes = bytes;
+    return UKFB_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter, const int64_t* ts_us,
                         const int32_t* meas_model, const double* z, const double* Q, uint32_t* status_or, int64_t* rounds) {
-    if (!e || n_events < 0 || (n_events > 0 && (!filter || !ts_us || !meas_model || !z || !Q)))
+    if (!e || n_events < 0 || n_events > 0x7fffffff || (n_events > 0 && (!filter || !ts_us || !meas_model || !z || !Q)))
         return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events: bad argument");
     HIP_TRY(hipSetDevice(e->device));
     if (status_or) *status_or = 0;
     if (rounds) *rounds = 0;
     if (n_events == 0) return UKFB_OK;
-    for (int64_t i = 0; i < n_events; ++i)
-        if (filter[i] < 0 || filter[i] >= e->cap || ts_us[i] < 0)
-            return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
-    // per filter: stable time order; the rank of a sample within its filter is its round.  Filter ids are dense,
-    // so this is a counting sort by filter (arrival order kept) followed by an insertion sort by time inside each
-    // (short) bucket: linear in the number of events, where a comparison sort of the whole stream was 2/3 of the call
-    std::vector<int64_t> order(static_cast<size_t>(n_events), 0);
-    std::vector<int64_t> round_of(static_cast<size_t>(n_events), 0);
-    int64_t nrounds = 0;
-    {
-        std::vector<int64_t> first(static_cast<size_t>(e->cap) + 1, 0);
-        for (int64_t i = 0; i < n_events; ++i) ++first[size_t(filter[i]) + 1];
-        for (int64_t f = 0; f < e->cap; ++f) first[size_t(f) + 1] += first[size_t(f)];
-        {
-            std::vector<int64_t> fill(first.begin(), first.end() - 1);
-            for (int64_t i = 0; i < n_events; ++i) order[size_t(fill[size_t(filter[i])]++)] = i;
-        }
-        for (int64_t f = 0; f < e->cap; ++f) {
-            const int64_t b0 = first[size_t(f)], b1 = first[size_t(f) + 1];
-            for (int64_t k = b0 + 1; k < b1; ++k) {   // stable insertion sort by timestamp
-                const int64_t cur = order[size_t(k)];
-                int64_t j = k;
-                while (j > b0 && ts_us[order[size_t(j - 1)]] > ts_us[cur]) {
-                    order[size_t(j)] = order[size_t(j - 1)];
-                    --j;
-                }
-                order[size_t(j)] = cur;
-            }
-            for (int64_t k = b0; k < b1; ++k) round_of[size_t(k)] = k - b0;
-            nrounds = std::max(nrounds, b1 - b0);
-        }
-    }
-    // samples grouped by round (counting sort), packed in engine precision into ONE pinned arena and uploaded with
-    // one copy; arena and device twin are kept by the engine and only ever grow
-    std::vector<int64_t> start(static_cast<size_t>(nrounds) + 1, 0);
-    for (int64_t k = 0; k < n_events; ++k) ++start[size_t(round_of[size_t(k)]) + 1];
-    for (int64_t r = 0; r < nrounds; ++r) start[size_t(r) + 1] += start[size_t(r)];
-    const size_t ne = static_cast<size_t>(n_events);
-    const size_t off_f = 0, off_t = off_f + ne * sizeof(int64_t), off_z = off_t + ne * sizeof(int64_t),
-                 off_q = off_z + ne * 3 * e->tsize, off_m = off_q + ne * 9 * e->tsize,
-                 bytes = ((off_m + ne * sizeof(int32_t) + 255) / 256) * 256;
-    if (bytes > e->ev_bytes) {
-        if (e->ev_host) HIP_TRY(hipHostFree(e->ev_host));
-        if (e->ev_dev) HIP_TRY(hipFree(e->ev_dev));
-        e->ev_host = e->ev_dev = nullptr;
-        e->ev_bytes = 0;
-        HIP_TRY(hipHostMalloc(&e->ev_host, bytes, hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&e->ev_dev, bytes));
-        e->ev_bytes = bytes;
-    }
-    if (!e->ev_acc) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ev_acc), size_t(e->cap) * sizeof(uint32_t)));
-    {
-        char* hb = static_cast<char*>(e->ev_host);
-        int64_t* pf = reinterpret_cast<int64_t*>(hb + off_f);
-        int64_t* pt = reinterpret_cast<int64_t*>(hb + off_t);
-        int32_t* pm = reinterpret_cast<int32_t*>(hb + off_m);
-        std::vector<int64_t> pos(start.begin(), start.end() - 1);
-        for (int64_t k = 0; k < n_events; ++k) {
-            const int64_t src = order[size_t(k)], dst = pos[size_t(round_of[size_t(k)])]++;
-            pf[dst] = filter[src];
-            pt[dst] = ts_us[src];
-            pm[dst] = meas_model[src];
-            if (e->prec == UKFB_F64) {
-                std::memcpy(reinterpret_cast<double*>(hb + off_z) + dst * 3, z + src * 3, 3 * sizeof(double));
-                std::memcpy(reinterpret_cast<double*>(hb + off_q) + dst * 9, Q + src * 9, 9 * sizeof(double));
-            } else {
-                convert(z + src * 3, reinterpret_cast<float*>(hb + off_z) + dst * 3, 3);
-                convert(Q + src * 9, reinterpret_cast<float*>(hb + off_q) + dst * 9, 9);
-            }
-        }
-    }
-    HIP_TRY(hipMemcpyAsync(e->ev_dev, e->ev_host, bytes, hipMemcpyHostToDevice, e->stream));
-    char* db = static_cast<char*>(e->ev_dev);
-    const int64_t* d_f = reinterpret_cast<const int64_t*>(db + off_f);
-    const int64_t* d_t = reinterpret_cast<const int64_t*>(db + off_t);
-    const int32_t* d_m = reinterpret_cast<const int32_t*>(db + off_m);
-    const void* d_z = db + off_z;
-    const void* d_q = db + off_q;
-    uint32_t* d_acc = e->ev_acc;
-    int rc = UKFB_OK;
-    HIP_TRY(hipMemsetAsync(d_acc, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
-    const int cap_blocks = int((e->cap + 255) / 256);
-    for (int64_t r = 0; r < nrounds; ++r) {
-        const int64_t lo = start[size_t(r)], cnt = start[size_t(r) + 1] - lo;
-        HIP_TRY(hipMemsetAsync(e->ts_stage, 0xFF, size_t(e->cap) * sizeof(int64_t), e->stream));     // -1: no sample
-        HIP_TRY(hipMemsetAsync(e->meas_stage, 0xFF, size_t(e->cap) * sizeof(int32_t), e->stream));   // -1: no measurement
-        const int blocks = int((cnt + 255) / 256);
-        if (e->prec == UKFB_F64)
-            hipLaunchKernelGGL(scatter_events_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, d_f + lo, d_t + lo, d_m + lo,
-                               static_cast<const double*>(d_z) + lo * 3, static_cast<const double*>(d_q) + lo * 9, cnt,
-                               e->ts_stage, e->meas_stage, static_cast<double*>(e->z_stage), static_cast<double*>(e->Q_stage));
-        else
-            hipLaunchKernelGGL(scatter_events_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, d_f + lo, d_t + lo, d_m + lo,
-                               static_cast<const float*>(d_z) + lo * 3, static_cast<const float*>(d_q) + lo * 9, cnt,
-                               e->ts_stage, e->meas_stage, static_cast<float*>(e->z_stage), static_cast<float*>(e->Q_stage));
-        rc = ukfb_cycle_timestamps_dev(e, e->ts_stage, e->meas_stage, e->z_stage, e->Q_stage);
-        if (rc) return rc;
-        hipLaunchKernelGGL(accumulate_status_kernel, dim3(cap_blocks), dim3(256), 0, e->stream, e->status, e->ts_stage, d_acc,
-                           e->cap);
-    }
-    HIP_TRY(hipMemcpyAsync(e->status, d_acc, size_t(e->cap) * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));   // the pinned arena may be reused by the next call
-    if (rounds) *rounds = nrounds;
-    if (status_or) return ukfb_get_status_summary(e, status_or);
-    return UKFB_OK;
+    // raw events go to the device as they are (one copy per array); ordering, conversion to the engine's
+    // precision and the per-round scatter all happen there
+    const size_t ne = size_t(n_events);
+    Carver raw(nullptr);
+    raw.take<int64_t>(ne); raw.take<int64_t>(ne); raw.take<int32_t>(ne); raw.take<double>(3 * ne); raw.take<double>(9 * ne);
+    int rc = ensure_events_arena(e, raw.used + events_workspace_bytes(n_events));
+    if (rc) return rc;
+    Carver c(e->ev_dev);
+    int64_t* d_f = c.take<int64_t>(ne);
+    int64_t* d_t = c.take<int64_t>(ne);
+    int32_t* d_m = c.take<int32_t>(ne);
+    double* d_z = c.take<double>(3 * ne);
+    double* d_q = c.take<double>(9 * ne);
+    HIP_TRY(hipMemcpyAsync(d_f, filter, ne * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_t, ts_us, ne * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_m, meas_model, ne * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_z, z, 3 * ne * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_q, Q, 9 * ne * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    rc = process_events_device<double>(e, n_events, d_f, d_t, d_m, d_z, d_q, c.used, status_or, rounds);
+    HIP_TRY(hipStreamSynchronize(e->stream));   // the caller's buffers are free again
+    return rc;
+}
+
+int ukfb_process_events_dev(ukfb_engine* e, int64_t n_events, const int64_t* filter_dev, const int64_t* ts_us_dev,
+                            const int32_t* meas_model_dev, const void* z_dev, const void* Q_dev, uint32_t* status_or,
+                            int64_t* rounds) {
+    if (!e || n_events < 0 || n_events > 0x7fffffff ||
+        (n_events > 0 && (!filter_dev || !ts_us_dev || !meas_model_dev || !z_dev || !Q_dev)))
+        return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events_dev: bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (status_or) *status_or = 0;
+    if (rounds) *rounds = 0;
+    if (n_events == 0) return UKFB_OK;
+    int rc = ensure_events_arena(e, events_workspace_bytes(n_events));
+    if (rc) return rc;
+    if (e->prec == UKFB_F64)
+        return process_events_device<double>(e, n_events, filter_dev, ts_us_dev, meas_model_dev, static_cast<const double*>(z_dev),
+                                             static_cast<const double*>(Q_dev), 0, status_or, rounds);
+    return process_events_device<float>(e, n_events, filter_dev, ts_us_dev, meas_model_dev, static_cast<const float*>(z_dev),
+                                        static_cast<const float*>(Q_dev), 0, status_or, rounds);
 }
 
 // ---- measurement of the engine ------------------------------------------------------------------

@@ -48,8 +48,7 @@ struct ukfb_engine {
     double* dt_stage = nullptr;
     int64_t* ts_stage = nullptr;
     uint32_t* reduce_word = nullptr;  // status OR-reduction target
-    // ukfb_process_events: pinned host arena and its device twin (grow-only), status accumulator [cap]
-    void* ev_host = nullptr;
+    // ukfb_process_events: device workspace (grow-only), status accumulator [cap]
     void* ev_dev = nullptr;
     size_t ev_bytes = 0;
     uint32_t* ev_acc = nullptr;

@@ -44,7 +44,7 @@ EXPORTS = [
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
     "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
-    "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events",
+    "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
 ]
 BODY_STATE_SCALARS = 49
 
@@ -316,6 +316,14 @@ class BatchUKF:
                                            t.ctypes.data_as(C.POINTER(C.c_int64)),
                                            m.ctypes.data_as(C.POINTER(C.c_int32)), _pd(z), _pd(Q), C.byref(st),
                                            C.byref(rounds)), "ukfb_process_events")
+        return int(st.value), int(rounds.value)
+
+    def process_events_dev(self, n_events: int, filter_dev, ts_us_dev, meas_model_dev, z_dev, Q_dev):
+        """The same stream already resident in HBM (int64, int64, int32, z / Q in the engine's precision)."""
+        st, rounds = C.c_uint32(0), C.c_int64(0)
+        _chk(self._lib.ukfb_process_events_dev(self._h, C.c_int64(int(n_events)), _devptr(filter_dev), _devptr(ts_us_dev),
+                                               _devptr(meas_model_dev), _devptr(z_dev), _devptr(Q_dev), C.byref(st),
+                                               C.byref(rounds)), "ukfb_process_events_dev")
         return int(st.value), int(rounds.value)
 
     # ---- measurement of the engine

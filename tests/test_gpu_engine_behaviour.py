@@ -349,3 +349,23 @@ def test_time_ordered_event_stream(spe, oracle, onp):
     assert (last_g == last).all()
     assert max_abs(m_g, m_o) <= 1e-9 and max_abs(c_g, c_o) <= 1e-9
     assert (st_g == st_o).all() and st_or == int(np.bitwise_or.reduce(st_o))
+    # the same stream resident in HBM, fp32 engine: ukfb_process_events_dev must reproduce the host-pointer entry
+    import torch
+    f_h = np.array([e_[0] for e_ in shuffled], dtype=np.int64); t_h = np.array([e_[1] for e_ in shuffled], dtype=np.int64)
+    m_h = np.array([e_[2] for e_ in shuffled], dtype=np.int32)
+    z_h = np.stack([e_[3] for e_ in shuffled]); Q_h = np.stack([e_[4] for e_ in shuffled])
+    for prec, td, tol in ((spe.F64, torch.float64, 0.0), (spe.F32, torch.float32, 0.0)):
+        e_host = spe.BatchPoseUKF(n, precision=prec); e_host.initialize(mu, cov)
+        ref = e_host.process_events(f_h, t_h, m_h, z_h, Q_h)
+        e_dev = spe.BatchPoseUKF(n, precision=prec); e_dev.initialize(mu, cov)
+        d = [torch.from_numpy(f_h).cuda(), torch.from_numpy(t_h).cuda(), torch.from_numpy(m_h).cuda(),
+             torch.from_numpy(z_h).to("cuda", td), torch.from_numpy(Q_h.reshape(-1, 9)).to("cuda", td)]
+        torch.cuda.synchronize()
+        got = e_dev.process_events_dev(len(shuffled), *d)
+        assert got == ref
+        (ma, ca, _), (mb, cb, _) = e_host.state(), e_dev.state()
+        assert max_abs(ma, mb) <= tol and max_abs(ca, cb) <= tol and (e_host.status() == e_dev.status()).all()
+        assert (e_host.last_measurement_time() == e_dev.last_measurement_time()).all()
+    # an out-of-range filter index is refused before anything is applied
+    with pytest.raises(spe.UkfbError):
+        eng.process_events([n], [2_000_000], [0], np.zeros((1, 3)), np.eye(3)[None])

@@ -27,3 +27,16 @@ for rep in range(3):
     e.sync()
     dt = time.perf_counter() - t0
     print("filters %d, events %d, rounds %d, status_or %d: %.1f ms -> %.1f M events/s" % (n, E, rounds, st, dt * 1e3, E / dt / 1e6))
+
+# the same stream resident in HBM (engine precision): ordering, ranking and scatter on the device
+td = torch.float64
+d = [torch.from_numpy(f).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(m).cuda(),
+     torch.from_numpy(z).to("cuda", td), torch.from_numpy(Q.reshape(-1, 9)).to("cuda", td)]
+for rep in range(3):
+    e.initialize(mu, cov); e.set_last_measurement_time(np.full(n, 1_000_000, dtype=np.int64)); e.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, rounds = e.process_events_dev(E, *d)
+    e.sync()
+    dt = time.perf_counter() - t0
+    print("device-resident: events %d, rounds %d, status_or %d: %.2f ms -> %.1f M events/s" % (E, rounds, st, dt * 1e3, E / dt / 1e6))

@@ -66,7 +66,11 @@ template <class T> struct KArgs {
     T mean_tol;
     int mean_max_it;
     T gate_chi2;                 // < 0: accept any
+#ifdef UKFB_STAMPS
+    unsigned long long* stamps;  // diagnostic build: [grid][UKFB_MAX_STAMPS] s_memtime per phase marker
+#endif
 };
+#define UKFB_MAX_STAMPS 32
 
 // LDS slice of one filter, in scalars of T.
 template <class T, class M> struct Layout {
@@ -303,10 +307,11 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 
     // ---- time gate (UnscentedKalmanFilter.hpp:83-125)
     bool do_p = false, p_error = false;
+    bool noev = false;   // ts < 0: this filter has no sample in this call -> neither predicted nor updated
     T dtT = T(0);
     if constexpr (DO_PREDICT) {
         double dt;
-        bool first = false, noev = false;
+        bool first = false;
         if (a.ts) {
             const int64_t last = a.last_ts[fc], ts = a.ts[fc];
             noev = ts < 0;                       // event streams: this filter has no sample in this call
@@ -331,7 +336,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
     if constexpr (DO_UPDATE) {
         mid = a.meas ? a.meas[fc] : a.meas_uniform;
         const bool act = M::meas_valid(mid) && (a.active ? a.active[fc] != 0 : true);
-        do_u = live && act && !p_error;
+        do_u = live && act && !p_error && !noev;
         st |= (live && !do_u) ? ST_INACTIVE : 0u;
     }
 

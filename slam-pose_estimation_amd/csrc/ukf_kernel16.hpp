@@ -183,6 +183,29 @@ template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layo
 // scheduling fence: keeps the machine scheduler from hoisting the next phase's loads / ALU work
 // across this point (it otherwise trades ~2x the registers for ILP and ends up spilling)
 UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
+// Phase markers (diagnostic builds only; the product build defines neither macro and they vanish):
+//   -DUKFB_PHASE_MARKS  an assembly comment between two scheduling barriers, read by tools/isa_phases.py
+//   -DUKFB_STAMPS       lane 0 stores s_memtime to KArgs::stamps[workgroup][marker] (tools/phase_stamps.sh:
+//                       time per phase of a wavefront's life, the dynamic counterpart of the static listing)
+#if defined(UKFB_STAMPS)
+enum { UKFB_STAMP_BASE = __COUNTER__ };
+#define UKFB_MARK(name)                                                                                          \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+        if (threadIdx.x == 0) a.stamps[size_t(blockIdx.x) * UKFB_MAX_STAMPS + (__COUNTER__ - UKFB_STAMP_BASE - 1)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#elif defined(UKFB_PHASE_MARKS)
+#define UKFB_MARK(name)                                         \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        asm volatile("; @@PHASE " name);                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#else
+#define UKFB_MARK(name) do { } while (0)
+#endif
 // Keeps a loaded value live in a VGPR so that "cond ? loaded : other" stays a v_cndmask; without it the
 // compiler sinks the LDS load into an exec-masked branch (s_and_saveexec / s_cbranch_execz per element).
 UKFB_DEV void keep(float& x) { asm volatile("" : "+v"(x)); }
@@ -359,6 +382,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     const bool has_pair = l < D;       // lane owns the sigma pair of column l
     const bool has_ctr = l == D;       // lane owns the centre point
 
+    UKFB_MARK("prologue");
     // ---- prologue: EVERY per-filter stream is requested before the first dependent instruction, so the kernel
     // pays the HBM latency once.  Optional streams (null pointer) are read from a substitute address that is
     // always valid and the value is dropped by a select - a branch here would serialise the round trips.
@@ -403,6 +427,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         zq_l = *zp;
     }
 
+    UKFB_MARK("stage");
     // ---- stage the filter in LDS: packed covariance, mean, measurement
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
@@ -416,12 +441,14 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     const bool live = fvalid && (init_b != 0);
     st |= (fvalid && !live) ? ST_UNINITIALISED : 0u;
 
+    UKFB_MARK("gate");
     // ---- time gate (UnscentedKalmanFilter.hpp:83-125)
     bool do_p = false, p_error = false, ts_store = false;
+    bool noev = false;   // ts < 0: this filter has no sample in this call -> neither predicted nor updated
     T dtT = T(0);
     if constexpr (DO_PREDICT) {
         const bool use_ts = a.ts != nullptr;
-        const bool noev = use_ts && (ts_l < 0);      // event streams: this filter has no sample in this call
+        noev = use_ts && (ts_l < 0);
         const bool first = use_ts && (last_l == 0) && !noev;
         const double dt_ts = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
         const double dt = use_ts ? dt_ts : (a.dt ? dt_l : a.dt_uniform);
@@ -449,7 +476,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     if constexpr (DO_UPDATE) {
         mid = a.meas ? mid_l : a.meas_uniform;
         const bool act = M::meas_valid(mid) && (a.active ? act_b != 0 : true);
-        do_u = live && act && !p_error;
+        do_u = live && act && !p_error && !noev;
         st |= (live && !do_u) ? ST_INACTIVE : 0u;
     }
     wsync();
@@ -462,6 +489,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     // =========================================================================== predict
     if constexpr (DO_PREDICT) {
         if (__any(do_p)) {
+            UKFB_MARK("p_chol");
             T xp[S], xm[S], ref[S];
             bool ok;
             {
@@ -485,16 +513,19 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     rs = chol16<T, D, LS>(arow, Lc, l, ok);
                     wsync();
                 }
+                UKFB_MARK("p_sigma");
                 T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
                 sigma_pair<T, M>(mu_r, col, xp, xm);
             }
+            UKFB_MARK("p_process");
             const bool pc = do_p && ok;            // this filter's predict will be committed
             sfence();
             process_fast((M*)nullptr, xp, pin);    // lanes >= D carry the centre point (their column is zero)
             sfence();
             process_fast((M*)nullptr, xm, pin);
             sfence();
+            UKFB_MARK("p_mean1");
             // propagated centre point (lane D): every lane starts the mean from it
 #pragma unroll
             for (int s = 0; s < S; ++s) ref[s] = row_bcast<D>(xp[s]);
@@ -568,6 +599,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     }
                 }
             }
+            UKFB_MARK("p_delta_e");
             // Euclidean part of the mean is final: write those delta columns now and drop the registers
             wsync();  // every lane is done with the factor columns (they alias the table)
             {
@@ -587,6 +619,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     if (s < Q || s >= Q + 4) dst[s] = ref[s];
             }
             sfence();
+            UKFB_MARK("p_mean_it");
             // ---- remaining iterations: SO(3) component only
             T qr[4] = {ref[Q], ref[Q + 1], ref[Q + 2], ref[Q + 3]};
             const T qp[4] = {xp[Q], xp[Q + 1], xp[Q + 2], xp[Q + 3]};
@@ -621,6 +654,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     active = active && more && !capped;
                 }
             }
+            UKFB_MARK("p_delta_r");
             {   // rotation deltas to the final mean; quaternion of the mean
                 T rp[3], rm[3];
                 rot_minus(qp, qr, rp);
@@ -635,6 +669,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 for (int k = 0; k < 4; ++k) dst[Q + k] = qr[k];
             }
             wsync();
+            UKFB_MARK("p_cov");
             // ---- covariance tiles: lane -> (r0, c0) of a TR x TC block with c0 <= r0 + TR - 1
             int r0 = -1, c0 = 0;
             {
@@ -713,6 +748,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                                           : process_noise_entry16<T, M>(a.Rn + fc * a.Rn_stride, a.Racc + fc * a.Rn_stride, ROT, a, pin, rc, cc);
                     PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = fma(T(0.5), acc[i2][j2], nv);
                 }
+            UKFB_MARK("p_end");
             // a gated / failed predict must leave the ORIGINAL state for the update and the commit:
             // re-stage it from HBM (rare path, wave-uniform guard)
             if (__any(fvalid && !p_commit)) {
@@ -732,6 +768,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     // =========================================================================== update
     if constexpr (DO_UPDATE) {
         if (__any(do_u)) {
+            UKFB_MARK("u_stats");
             T zin[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) zin[k] = ZQ[k];
@@ -946,6 +983,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 }
             }
             sfence();
+            UKFB_MARK("u_gain");
             T Kr[3], KSr[3];
             bool accept;
             {
@@ -964,6 +1002,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             const T del = Kr[0] * innov[0] + Kr[1] * innov[1] + Kr[2] * innov[2];
             sfence();
+            UKFB_MARK("u_downdate_chol");
             // ---- Sigma' = Sigma - (K S) K^T, row l on lane l; delta on every lane
             T srow2[D], d0[D];
             bool ok2;
@@ -987,6 +1026,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 wsync();
             }
             sfence();
+            UKFB_MARK("u_apply");
             // ---- applyDelta: mu' = mu [+] delta; only the SO(3) rows/columns are re-sampled
             T e0[4], rp[3], rm[3];
             {
@@ -1005,6 +1045,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 rot_minus(em, e0, rm);
             }
             sfence();
+            UKFB_MARK("u_rr_cross");
             // rotation-rotation block: 0.5 sum (r+ r+^T + r- r-^T)
             T rr[6];
 #pragma unroll
@@ -1042,6 +1083,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             u_commit = do_u && ok1 && ok2 && accept;
 
             sfence();
+            UKFB_MARK("u_assemble");
             // ---- assemble row l of the resampled covariance
             {
                 const bool lrot = (l >= RT) && (l < RT + 3);
@@ -1067,6 +1109,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 }
             }
             sfence();
+            UKFB_MARK("u_mean");
             // ---- new mean mu [+] delta (lane 0 writes the staging copy)
             {
                 T mu_r[S], nm[S];
@@ -1090,6 +1133,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         }
     }
 
+    UKFB_MARK("commit");
     // =========================================================================== commit
     const bool changed = p_commit || u_commit;
     if (changed && fvalid) {

@@ -2,6 +2,9 @@
 // per-(precision, model) translation units so that they compile in parallel.
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "ukf_engine.hpp"
 #include "ukf_kernel.hpp"
 #include "ukf_kernel16.hpp"
@@ -34,6 +37,59 @@ template <class T, class M, int G> static int launch_g(ukfb_engine* e, const Lau
     return UKFB_OK;
 }
 
+#ifdef UKFB_STAMPS
+// Diagnostic build (tools/phase_stamps.sh): every launch is synchronous; the per-marker s_memtime stamps of
+// all wavefronts are reduced to mean cycles between consecutive executed markers and appended to the file
+// named by UKFB_STAMP_OUT (one line per launch: kernel name, then marker_index:mean_delta pairs).
+template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds) {
+    static unsigned long long* dbuf = nullptr;
+    static size_t dcap = 0;
+    const size_t need = size_t(grid) * UKFB_MAX_STAMPS;
+    if (need > dcap) {
+        if (dbuf) (void)hipFree(dbuf);
+        if (hipMalloc(reinterpret_cast<void**>(&dbuf), need * 8) != hipSuccess) return UKFB_ERR_HIP;
+        dcap = need;
+    }
+    (void)hipMemsetAsync(dbuf, 0, need * 8, e->stream);
+    args.stamps = dbuf;
+    const dim3 gd((unsigned)grid), bd(64);
+    if (r.do_predict && r.do_update)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
+    else if (r.do_predict)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, e->stream, args);
+    else
+        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, e->stream, args);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return UKFB_ERR_HIP;
+    const char* path = getenv("UKFB_STAMP_OUT");
+    if (!path) return UKFB_OK;
+    std::vector<unsigned long long> h(need);
+    if (hipMemcpy(h.data(), dbuf, need * 8, hipMemcpyDeviceToHost) != hipSuccess) return UKFB_ERR_HIP;
+    double sum[UKFB_MAX_STAMPS] = {0};
+    int64_t cnt[UKFB_MAX_STAMPS] = {0};
+    double life = 0;
+    for (int64_t w = 0; w < grid; ++w) {
+        const unsigned long long* s = h.data() + size_t(w) * UKFB_MAX_STAMPS;
+        int prev = -1;
+        unsigned long long first = 0, last = 0;
+        for (int k = 0; k < UKFB_MAX_STAMPS; ++k) {
+            if (!s[k]) continue;
+            if (prev >= 0) { sum[prev] += double(s[k] - s[prev]); ++cnt[prev]; } else first = s[k];
+            prev = k;
+            last = s[k];
+        }
+        life += double(last - first);
+    }
+    if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "%s grid=%lld life=%.1f", e->last_kernel.c_str(), (long long)grid, life / double(grid));
+        for (int k = 0; k < UKFB_MAX_STAMPS; ++k)
+            if (cnt[k]) fprintf(f, " %d:%.1f", k, sum[k] / double(cnt[k]));
+        fprintf(f, "\n");
+        fclose(f);
+    }
+    return UKFB_OK;
+}
+#endif
+
 // tuned kernel: one DPP row per filter (ukf_kernel16.hpp)
 template <class T, class M> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
     constexpr int FPW = 4;
@@ -47,6 +103,9 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     e->last_grid = grid;
     if (grid == 0) return UKFB_OK;
     const dim3 gd((unsigned)grid), bd(64);
+#ifdef UKFB_STAMPS
+    return launch_row16_stamped<T, M>(e, r, args, grid, lds);
+#endif
     if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
     else if (r.do_predict)

@@ -2,28 +2,35 @@
 """bench.py -- UKF predict+update filter-cycles/s on MI355X (BASELINE.json's metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Self-launching: with N > 1 and no RANK in the environment this process starts N children (one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous) BEFORE anything touches the GPU, waits for them
+and relays rank 0's JSON line.  Under `python -m torch.distributed.run ... bench.py --gpus N` (RANK already set)
+it is one of the ranks.  N = 1 runs the same rank function in-process.
 
 One "step" = one fused launch of PoseUKF::predictionStep(dt) on the acceleration branch followed by
-integrateMeasurement(PositionMeasurement) for EVERY filter of the batch.  The
-workload is the configuration the metric is quoted on: 1 048 576 PoseWithVelocity filters per GPU, computed
-in fp64 (the reference's own arithmetic type).  Filters are independent, so ranks own disjoint filter ranges
-and there is no data-path collective; RCCL is used once, after the timed region, to gather the means.
-Default scaling is WEAK (every rank runs 1 048 576 filters, value = all filters x steps / time);
---scaling strong shards 1 048 576 filters in total over the ranks instead.  Inputs (acceleration,
-measurement, measurement covariance) are resident in HBM before the clock starts.
+integrateMeasurement(PositionMeasurement) for EVERY filter of this rank's shard.
+The workload is the configuration the metric is quoted on: 1 048 576 PoseWithVelocity filters, fp64 (the
+reference's own arithmetic type).  Default scaling is STRONG, the metric's "1 M filters on 1/2/4/8 GPUs":
+the filters are sharded over the ranks (131 072 per GPU at N = 8, BASELINE config 3's layout);
+`--scaling weak` gives every rank --filters filters instead.  Filters are independent
+(UnscentedKalmanFilter.hpp:150), so there is no data-path collective; RCCL is used once, after the timed
+region, to gather the means.  Inputs are resident in HBM before the clock starts.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     -- HBM roofline of the fused kernel from ALGORITHMIC bytes
-  cpu_baseline -- the CPU oracle (a from-scratch port, kind "port") timed on this host's cores
+  roofline     -- HBM roofline of the fused kernel from ALGORITHMIC bytes, the measured
+                  PMC traffic of this workload, and a VALU-issue roofline (`valu`) from the committed PMC pass
+  cpu_baseline -- the CPU oracle (a from-scratch port, kind "port") built -O3 -march=native on this host and
+                  timed on all hardware threads and on one core
+  parity       -- max |GPU - oracle| on a sample of filters after all launches of this run (same inputs)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -31,9 +38,14 @@ if ROOT not in sys.path:
 
 TOTAL_FILTERS = 1_048_576
 DT = 0.01
-ALG_SCALARS_POSE = 2 * 157 + 15  # read+write (13 + 144) + acc 3 + z 3 + Q 9
+ALG_SCALARS_POSE = 2 * 157 + 15    # read+write (13 + 144) + acc 3 + z 3 + Q 9
 ALG_SCALARS_ORIENT = 2 * 183 + 18  # read+write (14 + 169) + gyro 3 + acc 3 + z 3 + Q 9
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 1024                      # 256 CUs x 4 SIMDs
+N_RING = 4                         # input sets the steps cycle through
+SUSTAINED_STEPS = 500
+BURST_STEPS = 20
+TOL = {"f64": 1e-9, "f32": 1e-4}   # north_star
 
 
 class _DevArray:
@@ -50,105 +62,258 @@ def parse():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--filters", type=int, default=TOTAL_FILTERS,
-                    help="filters per GPU (weak scaling, default) or in total (--scaling strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: every rank runs --filters filters (N x --filters in total); strong: --filters "
-                         "filters are sharded evenly over the ranks (the literal '1 M filters on 1/2/4/8 GPUs')")
+                    help="filters in total (--scaling strong, default) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: --filters filters are sharded evenly over the ranks (the metric's '1 M filters on "
+                         "1/2/4/8 GPUs'); weak: every rank runs --filters filters (N x --filters in total)")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extra-regions", action="store_true", help="skip the sustained / burst kernel timings")
     ap.add_argument("--workload", choices=["pose", "pose-mixed", "orient"], default="pose",
                     help="pose: the headline metric (default). pose-mixed: BASELINE config 5 (per-filter model id over "
                          "the 9 Pose models, 25 %% inactive). orient: config 4 (OrientationState predict + body-velocity update)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of "
                     "the N>1 plumbing on a box with fewer GPUs than ranks)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="rehearse launch / rendezvous / sharding / barrier / gather with NO engine and NO timing "
+                         "(CPU boxes; prints value null)")
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
-    ap.add_argument("--cpu-sample-seconds", type=float, default=10.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=8.0, help="target CPU time of the all-core sample")
+    ap.add_argument("--parity-sample", type=int, default=4096)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(args):
+    """One child process per rank, started before this process has made any GPU call (it never does)."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "UKFB_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    rc = 0
+    out0 = ""
+    try:
+        pending = set(range(args.gpus))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:      # a dead rank would leave the others in a barrier forever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------- CPU legs
+def _threads_available():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(args):
-    """Time the oracle (reported baseline only; never the product path)."""
+    """Time the oracle (reported baseline only; never the product path): all hardware threads, then one core."""
+    import numpy as np
     from oracle import capi
     import slam_pose_estimation_amd as spe
-    n = args.cpu_sample_filters
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(avail, capi.max_threads(), 16))
-    mu, cov = spe.synth.pose_initial(n)
+    native = capi.native_lib()
+    build = "-O3 -march=native -fopenmp (built on this host)" if native is not None else \
+        "-O3 -march=x86-64-v3 -ffp-contract=off (native build failed)"
+    prec = 0 if args.precision == "f64" else 1
     R = spe.synth.pose_default_process_noise()
     acc_cov = 0.01 * np.eye(3)
-    prec = 0 if args.precision == "f64" else 1
-    inputs = [spe.synth.pose_cycle_inputs(n, k, mu[:, :3]) for k in range(4)]
-    # untimed touch
-    capi.pose_predict(mu[:64], cov[:64], R, inputs[0][0][:64], acc_cov, DT, prec=prec, threads=1)
-    cycles, el = 0, 0.0
-    t0 = time.perf_counter()
-    while el < args.cpu_sample_seconds and cycles < 2000:   # bounded sample: about 10 s of all-core CPU work
-        acc, z, Q = inputs[cycles % 4]
-        mu, cov, _ = capi.pose_predict(mu, cov, R, acc, acc_cov, DT, prec=prec, threads=threads)
-        mu, cov, _ = capi.pose_update(mu, cov, 0, z, Q, prec=prec, threads=threads)
-        cycles += 1
-        el = time.perf_counter() - t0
-    return {"value": n * cycles / el, "unit": "filter-cycles/s", "cores": threads, "kind": "port",
-            "sample": f"{n} PoseWithVelocity filters x {cycles} predict(acc)+position-update cycles, "
-                      f"{args.precision}, oracle/ukf_oracle.hpp with OpenMP over filters, {el:.2f} s"}
+
+    def run(n, threads, seconds):
+        mu, cov = spe.synth.pose_initial(n)
+        inputs = [spe.synth.pose_cycle_inputs(n, k, mu[:, :3]) for k in range(N_RING)]
+        capi.pose_predict(mu[:64], cov[:64], R, inputs[0][0][:64], acc_cov, DT, prec=prec, threads=1)   # untimed touch
+        cycles, el = 0, 0.0
+        t0 = time.perf_counter()
+        while el < seconds and cycles < 2000:
+            acc, z, Q = inputs[cycles % N_RING]
+            mu, cov, _ = capi.pose_predict(mu, cov, R, acc, acc_cov, DT, prec=prec, threads=threads)
+            mu, cov, _ = capi.pose_update(mu, cov, 0, z, Q, prec=prec, threads=threads)
+            cycles += 1
+            el = time.perf_counter() - t0
+        return n * cycles / el, cycles, el
+
+    with capi.using(native if native is not None else capi.lib()):
+        threads = max(1, min(_threads_available(), capi.max_threads()))
+        n_all = args.cpu_sample_filters
+        v_all, c_all, e_all = run(n_all, threads, args.cpu_sample_seconds)
+        n_one = max(64, min(n_all, 4096))
+        v_one, c_one, e_one = run(n_one, 1, args.cpu_sample_seconds / 2)
+    return {"value": v_all, "unit": "filter-cycles/s", "cores": threads, "kind": "port",
+            "single_core": {"value": v_one, "cores": 1,
+                            "sample": f"{n_one} filters x {c_one} cycles, {e_one:.2f} s"},
+            "build": build,
+            "sample": f"{n_all} PoseWithVelocity filters x {c_all} predict(acc)+position-update cycles, "
+                      f"{args.precision}, oracle/ukf_oracle.hpp with OpenMP over filters on {threads} hardware threads, "
+                      f"{e_all:.2f} s"}
 
 
-def load_traffic(kernel_name, filters_per_launch):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one matches this workload."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def parity_check(args, spe, eng, first, sample, cycles, orient):
+    """GPU state of filters [first, first+sample) of this rank against an oracle replay of the SAME launches:
+    `cycles` fused cycles over the input ring, starting from the synthetic initial state."""
+    import numpy as np
+    from oracle import capi
+    sy = spe.synth
+    f32 = (lambda x: x.astype(np.float32).astype(np.float64)) if args.precision == "f32" else (lambda x: x)
+    threads = max(1, min(_threads_available(), capi.max_threads()))
+    m_g, c_g, _ = eng.state(0, sample)
+    if orient:
+        mu, cov = sy.orient_initial(sample, first=first)
+        ring = [sy.orient_cycle_inputs(sample, k, mu[:, :4], first=first) for k in range(N_RING)]
+        m_o, c_o = f32(mu), f32(cov)
+        for k in range(cycles):
+            gyro, acc, z, Q = ring[k % N_RING]
+            m_o, c_o, _ = capi.orient_predict(m_o, c_o, sy.orient_process_noise(), f32(acc), f32(gyro), sy.ORIENT_TAU,
+                                              sy.ORIENT_TAU, eng.earth_rotation, DT, threads=threads)
+            m_o, c_o, _ = capi.orient_update(m_o, c_o, f32(z), f32(Q), threads=threads)
+    else:
+        mixed = args.workload == "pose-mixed"
+        mu, cov = sy.pose_initial(sample, first=first)
+        ring = []
+        for k in range(N_RING):
+            acc, z, Q = sy.pose_cycle_inputs(sample, k, mu[:, :3], first=first, random_q=mixed)
+            models = 0
+            if mixed:
+                models = sy.pose_mixed_models(sample, k, first=first)
+                z = sy.pose_measurement_for_model(mu, models, z - mu[:, :3])
+            ring.append((acc, z, Q, models))
+        R = sy.pose_default_process_noise()
+        acc_cov = 0.01 * np.eye(3)
+        m_o, c_o = f32(mu), f32(cov)
+        for k in range(cycles):
+            acc, z, Q, models = ring[k % N_RING]
+            m_o, c_o, _ = capi.pose_predict(m_o, c_o, R, f32(acc), acc_cov, DT, threads=threads)
+            m_o, c_o, _ = capi.pose_update(m_o, c_o, models, f32(z), f32(Q), threads=threads)
+    em, ec = float(np.abs(m_g - m_o).max()), float(np.abs(c_g - c_o).max())
+    tol = TOL[args.precision]
+    return {"max_abs_mu": em, "max_abs_cov": ec, "tol": tol, "ok": bool(em <= tol and ec <= tol),
+            "sample": f"filters {first}..{first + sample - 1} after {cycles} fused cycles of this run (pre-roll + warm-up + "
+                      f"timed), GPU state vs oracle/ukf_oracle.hpp (fp64) replay of the same input ring"}
+
+
+def load_profile_entry(name, kernel_name, filters_per_launch):
+    """Committed rocprofv3 --pmc results (profiles/<name>): the entry measured for this kernel and launch size."""
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
             doc = json.load(fh)
+        best = None
         for t in doc.get("entries", []):
-            if t.get("kernel") == kernel_name and int(t.get("filters_per_launch", -1)) == int(filters_per_launch):
-                return float(t["hbm_bytes_per_launch"])
+            if t.get("kernel") != kernel_name:
+                continue
+            if int(t.get("filters_per_launch", -1)) == int(filters_per_launch):
+                return t, True
+            best = best or t
+        return best, False
     except Exception:
-        pass
-    return None
+        return None, False
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
+    import numpy as np
     import torch
     import slam_pose_estimation_amd as spe
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+    if "RANK" in os.environ and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    # UKFB_BENCH_FORCE_DIST=1 under torchrun: rehearsal of the N>1 plumbing (RCCL init, barrier, all_reduce,
-    # gather) with a single rank on a one-GPU box
-    if world > 1 or ("RANK" in os.environ and os.environ.get("UKFB_BENCH_FORCE_DIST")):
+    # a process group exists whenever a launcher set RANK (also with one rank: rehearsal of the N>1 plumbing)
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("UKFB_BENCH_FORCE_DIST"))
+    have_gpu = (not args.plumbing_only) and torch.cuda.device_count() > 0
+    if not have_gpu and not args.plumbing_only:
+        raise SystemExit("bench.py: no HIP device visible -- the engine has no CPU path (use --plumbing-only to "
+                         "rehearse the multi-rank plumbing on a CPU box)")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if have_gpu else 0
+    if have_gpu:
+        torch.cuda.set_device(dev_index)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dev_index = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=args.backend)
-    else:
-        dev_index = 0
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", dev_index)
+    dev = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
+    coll_dev = dev if (args.backend == "nccl" and have_gpu) else torch.device("cpu")
 
     prec = spe.F64 if args.precision == "f64" else spe.F32
     tdtype = torch.float64 if prec == spe.F64 else torch.float32
     total = args.filters * world if args.scaling == "weak" else args.filters
     first, per = spe.shard_range(total, world, rank)
+    orient = args.workload == "orient"
+    S = 14 if orient else 13
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        if have_gpu:
+            torch.cuda.synchronize()
+
+    def rank_stats(x):
+        """(min, max) over ranks of a per-rank float."""
+        if dist is None:
+            return x, x
+        t = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        t[rank] = x
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.min().item()), float(t.max().item())
+
+    if args.plumbing_only:
+        # launch, rendezvous, sharding, barrier, all-reduce and the ragged gather -- no engine, no number
+        fence()
+        lo, hi = rank_stats(float(rank))
+        mu_local = torch.full((per, S), float(rank), dtype=tdtype)
+        gathered = spe.gather_means(mu_local, total, world, dist)
+        assert gathered.shape == (total, S) and (lo, hi) == (0.0, float(world - 1))
+        counts = [spe.shard_range(total, world, r)[1] for r in range(world)]
+        assert all(float(gathered[sum(counts[:r]), 0]) == float(r) for r in range(world) if counts[r])
+        if rank == 0:
+            print(json.dumps({"metric": "UKF predict+update filter-cycles/s", "value": None, "unit": "filter-cycles/s",
+                              "n_gpus": world, "plumbing_only": True, "backend": args.backend, "scaling": args.scaling,
+                              "config": {"workload": "none (rank plumbing rehearsal)", "filters": total,
+                                         "filters_per_gpu": per}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
 
     # ---- build the shard (host generation in chunks, then resident in HBM)
     CH = 131072
-    n_ring = 4
-    orient = args.workload == "orient"
-    S = 14 if orient else 13
     if orient:
         sy = spe.synth
         eng = spe.BatchOrientationUKF(per, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec,
@@ -156,11 +321,11 @@ def main():
         eng.set_process_noise(sy.orient_process_noise())
     else:
         eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
-    acc_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)]
-    gyr_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)] if orient else None
-    z_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(n_ring)]
-    Q_d = [torch.empty((per, 9), dtype=tdtype, device=dev) for _ in range(n_ring)]
-    m_d = [torch.empty((per,), dtype=torch.int32, device=dev) for _ in range(n_ring)] if args.workload == "pose-mixed" else None
+    acc_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(N_RING)]
+    gyr_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(N_RING)] if orient else None
+    z_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(N_RING)]
+    Q_d = [torch.empty((per, 9), dtype=tdtype, device=dev) for _ in range(N_RING)]
+    m_d = [torch.empty((per,), dtype=torch.int32, device=dev) for _ in range(N_RING)] if args.workload == "pose-mixed" else None
     for lo in range(0, per, CH):
         hi = min(per, lo + CH)
         if orient:
@@ -168,7 +333,7 @@ def main():
         else:
             mu, cov = spe.synth.pose_initial(hi - lo, first=first + lo)
         eng.initialize(mu, cov, first=lo)
-        for k in range(n_ring):
+        for k in range(N_RING):
             if orient:
                 gyro, acc, z, Q = spe.synth.orient_cycle_inputs(hi - lo, k, mu[:, :4], first=first + lo)
                 gyr_d[k][lo:hi] = torch.from_numpy(gyro).to(dev, tdtype)
@@ -186,47 +351,55 @@ def main():
         eng.set_acceleration(None, 0.01 * np.eye(3))
     torch.cuda.synchronize()
 
-    def step(k):
-        r = k % n_ring
+    done = [0]   # fused cycles applied to the engine so far (the parity replay needs the exact count)
+
+    def step():
+        r = done[0] % N_RING
         if orient:
             eng.bind_orient_inputs_dev(gyr_d[r], acc_d[r])
             eng.cycle_dev(DT, spe.MEAS_ORIENT_BODYVEL3, z_d[r], Q_d[r])
         else:
             eng.bind_acceleration_dev(acc_d[r])
             eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r], meas_model_dev=m_d[r] if m_d else None)
+        done[0] += 1
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def kernel_region(k):
+        """mean kernel time (ms) of k back-to-back launches: HIP events on the engine's stream"""
+        eng.timer_begin()
+        for _ in range(k):
+            step()
+        return eng.timer_end() / k
 
     # Untimed pre-roll: the FIRST burst of queued launches in a process is reported complete ~50 ms late by the
     # runtime in about one process out of three (GPU timestamps show the kernels back to back; later bursts
     # never, tools/sync_latency.py and DESIGN.md section 5).  A short burst (up to 64 launches)
     # absorbs that one-time event before the W warm-up steps and the K timed steps.
-    for k in range(min(args.steps, 64)):
-        step(k)
+    for _ in range(min(args.steps, 64)):
+        step()
     fence()
-    for k in range(args.warmup):
-        step(k)
+    for _ in range(args.warmup):
+        step()
     fence()
     eng.timer_begin()           # HIP events on the stream the kernel is launched on
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    t_launch = time.perf_counter()
+    for _ in range(args.steps):
+        step()
     kernel_ms_total = eng.timer_end()
-    t_event = time.perf_counter()
     fence()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("UKFB_BENCH_DEBUG"):
-        print("launch %.2f ms, event sync %.2f ms, fence %.2f ms, gpu %.2f ms" % (
-            (t_launch - t0) * 1e3, (t_event - t_launch) * 1e3, (t0 + elapsed - t_event) * 1e3, kernel_ms_total), file=sys.stderr)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    rank_lo, rank_hi = rank_stats(elapsed_local / args.steps * 1e3)
     status_or = eng.status_summary()
+
+    # ---- in-run parity on rank 0's first filters (before anything else advances the state)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        sample = min(args.parity_sample, per)
+        parity = parity_check(args, spe, eng, first, sample, done[0], orient)
 
     # ---- result gather over RCCL/xGMI (outside the timed region; means only)
     gather_ms = None
@@ -241,14 +414,43 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert gathered.shape == (total, S)
+        del gathered
+
+    # ---- kernel time under sustained clocks and in a burst (a 20-step timed region alone shows neither)
+    kernel_ms = kernel_ms_total / args.steps
+    sustained_ms = burst_ms = None
+    if not args.no_extra_regions:
+        sustained_ms = kernel_ms if args.steps >= SUSTAINED_STEPS else kernel_region(SUSTAINED_STEPS)
+        eng.sync()
+        time.sleep(1.0)    # let the clocks recover
+        burst_ms = kernel_region(BURST_STEPS)
+        fence()
 
     info = eng.last_launch_info()
     if rank == 0:
         tsize = 8 if prec == spe.F64 else 4
         value = total * args.steps / elapsed
         alg_bytes_launch = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * tsize * per
-        kernel_ms = kernel_ms_total / args.steps
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        traffic_e, exact = load_profile_entry("traffic_latest.json", info["kernel"], per)
+        traffic = None
+        if traffic_e is not None:   # bytes per launch scale with the filters of the launch (per-filter streams only)
+            traffic = float(traffic_e["hbm_bytes_per_launch"]) * (1.0 if exact else per / float(traffic_e["filters_per_launch"]))
+        pmc_e, _ = load_profile_entry("pmc_latest.json", info["kernel"], per)
+        valu = None
+        if pmc_e is not None:
+            # VALU-issue roofline: wave-instructions per launch x issue cycles per instruction, against what the
+            # SIMDs can issue during the kernel's measured duration at the clock the PMC pass observed
+            # (GRBM_GUI_ACTIVE / 8 / kernel time, MI355X_MICROARCH.md "DVFS give-back")
+            waves = (per + info["filters_per_workgroup"] - 1) // info["filters_per_workgroup"]
+            cyc = float(pmc_e["issue_cycles_per_valu_inst"])
+            clock_hz = float(pmc_e["clock_mhz"]) * 1e6
+            need = float(pmc_e["valu_insts_per_wave"]) * waves * cyc
+            have = N_SIMD * clock_hz * kernel_ms * 1e-3
+            valu = {"bound": "valu-issue", "valu_insts_per_wave": pmc_e["valu_insts_per_wave"],
+                    "issue_cycles_per_inst": cyc, "clock_mhz": pmc_e["clock_mhz"], "simds": N_SIMD,
+                    "achieved": need / (kernel_ms * 1e-3) / 1e12, "peak": N_SIMD * clock_hz / 1e12,
+                    "unit": "T issue-cycles/s", "frac": need / have, "source": pmc_e.get("source")}
         out = {
             "metric": "UKF predict+update filter-cycles/s, " + ("OrientationState" if orient else "PoseWithVelocity") + " filters",
             "value": value,
@@ -272,12 +474,19 @@ def main():
                        "parallelism": f"filter-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(info["kernel"], per),
+                         "traffic": traffic,
                          "kernel": info["kernel"], "kernel_ms_per_launch": kernel_ms,
+                         "kernel_ms_per_launch_sustained": sustained_ms, "kernel_ms_per_launch_burst": burst_ms,
+                         "frac_sustained": (alg_bytes_launch / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sustained_ms else None,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "lds_bytes_per_workgroup": info["lds_bytes"]},
+                         "lds_bytes_per_workgroup": info["lds_bytes"],
+                         "valu": valu},
             "status_or": status_or,
+            "rccl_ranks": (dist.get_world_size() if (dist is not None and args.backend == "nccl") else None),
+            "backend": (args.backend if dist is not None else None),
+            "ms_per_step_rank_min": rank_lo, "ms_per_step_rank_max": rank_hi,
             "gather_ms": gather_ms,
+            "parity": parity,
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "pose":
             out["cpu_baseline"] = cpu_baseline(args)
@@ -288,7 +497,15 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_children(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -41,6 +41,39 @@ def lib():
     return _lib
 
 
+def native_lib():
+    """-O3 -march=native build of the same oracle for bench.py's cpu_baseline leg, compiled on THIS host (the
+    GPU box's CPU differs from the build container's, so the library is never shipped).  None if g++ fails."""
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"ukf_oracle_native_{os.getuid()}", "libukf_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "native", f"NATIVE_OUT={out}"])
+        h = C.CDLL(out)
+        h.ukfo_earthw.restype = C.c_double
+        h.ukfo_max_threads.restype = C.c_int
+        return h
+    except Exception:
+        return None
+
+
+class using:
+    """Context manager: route the wrappers of this module through another build of the oracle library."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.prev, _lib = _lib, self.handle
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
 def default_config(**over) -> Config:
     c = Config()
     lib().ukfo_default_config(C.byref(c))

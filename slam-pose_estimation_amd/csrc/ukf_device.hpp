@@ -182,6 +182,34 @@ template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
 }
 
 
+// The same map for a quaternion whose norm `nrm` is known (products of the mean's orientation with unit
+// exponentials all have the mean's norm; MTK's atan(|vec| / w) is scale invariant, so the norm must be honoured,
+// not assumed to be 1).  With the norm at hand the first half-angle step tan(phi/2) = |vec| / (w + |q|) costs one
+// addition, so the polynomial covers rotation angles up to ~60 degrees (tan^2(phi/2) <= 0.07) instead of ~30:
+//   log q = 4 atan(t1)/|vec| vec = 4 [atan(t1)/t1] / (w + |q|) vec.
+// Beyond that (wave-uniform branch) two more half-angle steps; w < 0 goes through |w| and MTK's sign.
+template <class T> UKFB_DEV void so3_log_fast_n(const T (&q)[4], T nrm, T (&r)[3]) {
+    const T v2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const T w = q[3];
+    const T r1 = fast_rcp(w + nrm);
+    const T t1 = v2 * r1 * r1;                           // tan^2(phi/2)
+    T s = T(4) * r1 * poly_atan_ratio(t1);
+    const bool big = !(t1 <= Poly<T>::U_SMALL);          // also w + |q| <= 0 (angle >= pi) and NaN
+    if (__any(big)) {
+        const T r1b = fast_rcp(m_abs(w) + nrm);
+        const T t1b = v2 * r1b * r1b;                    // tan^2(phi/2) <= 1 with phi = atan(|vec| / |w|)
+        const T q2 = T(1) + t1b;
+        const T r2 = fast_rcp(T(1) + q2 * fast_rsqrt(q2));
+        const T t2 = t1b * r2 * r2;                      // tan^2(phi/4) <= 0.172
+        const T q3 = T(1) + t2;
+        const T r3 = fast_rcp(T(1) + q3 * fast_rsqrt(q3));
+        const T t3 = t2 * r3 * r3;                       // tan^2(phi/8) <= 0.0396
+        const T sb = T(16) * (r1b * r2) * r3 * poly_atan_ratio(t3);
+        s = big ? ((w < T(0)) ? -sb : sb) : s;
+    }
+    r[0] = s * q[0]; r[1] = s * q[1]; r[2] = s * q[2];
+}
+
 // MTK cos_sinc_sqrt: (cos(sqrt(x2)), sin(sqrt(x2))/sqrt(x2)), three Taylor pairs below eps^(1/4).
 template <class T> UKFB_DEV void cos_sinc_sqrt(T x2, T& c, T& s) {
     T cosi = T(1), sinc = T(1);

@@ -107,6 +107,18 @@ template <class T> struct MT<PoseM<T>> {
                                                nib(6, 15) | nib(7, 15) | nib(8, 12);
     static constexpr bool HAS_EUCLID_MEAS = true;
     static constexpr int ZCOLS = 6;   // tangent columns that can move an orientation-dependent measurement (p, q)
+    // Prediction (PoseUKF.cpp:75-97): position and orientation (tangent 0..5) are nonlinear in the state; velocity and
+    // angular velocity (6..11) are affine with unit scale (v + acc dt, omega).  Covariance work items of the 16 lanes
+    // (first tangent row / column of the lane's TR x TC tile, one nibble per lane): lanes 0..9 = the five tiles of the
+    // nonlinear 6x6 block, two lanes per tile (each sums half of the sigma points); lanes 10..15 = the cross block.
+    static constexpr unsigned long long TILE_R = nib(0, 0) | nib(1, 0) | nib(2, 2) | nib(3, 2) | nib(4, 2) | nib(5, 2) | nib(6, 4) |
+                                                 nib(7, 4) | nib(8, 4) | nib(9, 4) | nib(10, 6) | nib(11, 6) | nib(12, 8) |
+                                                 nib(13, 8) | nib(14, 10) | nib(15, 10);
+    static constexpr unsigned long long TILE_C = nib(0, 0) | nib(1, 0) | nib(2, 0) | nib(3, 0) | nib(4, 3) | nib(5, 3) | nib(6, 0) |
+                                                 nib(7, 0) | nib(8, 3) | nib(9, 3) | nib(10, 0) | nib(11, 3) | nib(12, 0) |
+                                                 nib(13, 3) | nib(14, 0) | nib(15, 3);
+    static constexpr int WORK_LANES = 16;
+    UKFB_DEV static T aff_scale(int, const ProcIn<T>&) { return T(1); }
     // orientation-dependent measurement (model id 3, PoseUKF.cpp:28-33): the quaternion itself.
     // qp / qm / q0: orientation of the +column, -column and centre sigma point.
     UKFB_DEV static void gen_measure(const T (&qp)[4], const T (&qm)[4], const T (&q0)[4], const T*, const T*, T,
@@ -120,6 +132,17 @@ template <class T> struct MT<OrientM<T>> {
     static constexpr unsigned long long SEL0 = 0, SEL1 = 0, SEL2 = 0;
     static constexpr bool HAS_EUCLID_MEAS = false;
     static constexpr int ZCOLS = 6;   // body velocity q^-1 v reads the orientation (0..2) and the velocity (3..5)
+    // Prediction (OrientationUKF.cpp:12-32): orientation and velocity (tangent 0..5) are nonlinear; the biases (6..11)
+    // and gravity (12) are affine with diagonal scale (1 - dt / tau), 1.  3x3 tiles: lanes 0..5 = the three tiles of the
+    // nonlinear block, two lanes per tile; lanes 6..11 = the cross block; lanes 12..15 repeat lane 0 and store nothing.
+    static constexpr unsigned long long TILE_R = nib(0, 0) | nib(1, 0) | nib(2, 3) | nib(3, 3) | nib(4, 3) | nib(5, 3) | nib(6, 6) |
+                                                 nib(7, 6) | nib(8, 9) | nib(9, 9) | nib(10, 12) | nib(11, 12);
+    static constexpr unsigned long long TILE_C = nib(0, 0) | nib(1, 0) | nib(2, 0) | nib(3, 0) | nib(4, 3) | nib(5, 3) | nib(6, 0) |
+                                                 nib(7, 3) | nib(8, 0) | nib(9, 3) | nib(10, 0) | nib(11, 3);
+    static constexpr int WORK_LANES = 12;
+    UKFB_DEV static T aff_scale(int c, const ProcIn<T>& in) {
+        return (c < 9) ? fma(in.dt, in.ninv_tau_g, T(1)) : ((c < 12) ? fma(in.dt, in.ninv_tau_a, T(1)) : T(1));
+    }
     // velocityMeasurementModel (OrientationUKF.cpp:34-39): q.inverse() * v for the three sigma points;
     // the velocity (stored 4..6, tangent 3..5) comes straight from the mean staging and the factor column
     UKFB_DEV static void body_vel(const T (&q)[4], const T (&v)[3], T (&z)[4]) {
@@ -150,25 +173,31 @@ template <class T, class M> struct Layout16 {
     // 14 scalars = 14 / 28 dwords: lanes 0..15 fall on distinct banks in both precisions (a stride of 12 or 16
     // scalars repeats after 8 resp. 2 lanes; measured +3..10 % on the fused cycle).
     static constexpr int LS = 14;
-    // row stride of the W / K / cross-term exchange (4 used), conflict-free for the same reason
-    static constexpr int WS = 4;
     static constexpr int al(int x) { return (x + VEC - 1) / VEC * VEC; }
     static constexpr int PKP = al(PK);
+    // Prediction tables.  Only the NL = 6 leading tangent components are nonlinear in the state for both models
+    // (MT<M>), so the delta table holds 6 columns; the affine rows of the factor and the half differences
+    // W_l = (delta+_l - delta-_l) / 2 serve the cross block.  Row stride ST (6 / 7 scalars): lane-strided b64 / b32
+    // accesses of lanes 0..15 fall on distinct banks, and D - NL <= ST.  Every table has one extra all-zero row so
+    // that all lanes run the same trip count D + 1 (N + 1 = 2 (D + 1) rows of deltas in two halves).
+    static constexpr int NL = 6, ST = (D == 12) ? 6 : 7, TRIP = D + 1;
     static constexpr int LC = 0;                            // D*LS : unscaled factor columns
-    static constexpr int DXT = 0;                           // N*LS : delta table (aliases LC and PKS)
-    static constexpr int PKS = al(D * LS);                  // PKP  : packed covariance staging
-    static constexpr int MISC = al(N * LS);
+    // delta table rows 0..N-1 alias the factor (dead once every lane holds its column); its zero row lies behind it
+    static constexpr int TNL = (D * LS > N * ST) ? (D * LS - N * ST) : 0;
+    static constexpr int PKS = al(TNL + (N + 1) * ST);      // PKP  : packed covariance staging (survives the prediction)
+    static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor
+    static constexpr int WT = LAF + al((D + 1) * ST);       // (D+1)*ST : row l = W_l
+    static constexpr int MISC = WT + al((D + 1) * ST);
     static constexpr int MUS = MISC;                        // 16 : mean staging
     static constexpr int ROT = MISC + 16;                   // 12 : rotation matrix of the mean
     static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
-    static constexpr int WK = MISC + 40;                    // D*WS (<= 80): W / K / cross-term exchange
-    static constexpr int DUM = MISC + 120;                  // 16 : sink for lane-predicated stores
-    static constexpr int PF_RAW = MISC + 136;
+    static constexpr int DUM = MISC + 40;                   // 16 : sink for lane-predicated stores
+    static constexpr int PF_RAW = MISC + 56;
     // the four slices of a wavefront must not start on the same LDS bank (measured: a slice stride that is
     // a multiple of 32 dwords costs 25-50 %: every broadcast read becomes a 4-way conflict)
     static constexpr int PF = PF_RAW + (((PF_RAW * int(sizeof(T)) / 4) % 32 == 0) ? 2 * VEC : 0);
-    static_assert(PKS + PKP <= MISC, "packed staging must fit behind the factor");
-    static_assert(D * WS <= 80 && PF % VEC == 0 && LS >= D && LS <= 16 && S <= 16, "scratch layout");
+    static_assert(TNL + N * ST >= D * LS && D - NL <= ST && NL <= ST, "prediction tables");
+    static_assert(PF % VEC == 0 && LS >= D && LS <= 16 && S <= 16 && D + 1 <= 16, "scratch layout");
 };
 
 template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layout16<T, M>::PF * int(sizeof(T)); }
@@ -260,6 +289,14 @@ template <class T> UKFB_DEV void rot_minus(const T (&qx)[4], const T (&qy)[4], T
     T d[4];
     quat_mul(oc, qx, d);
     so3_log_fast(d, r);
+}
+
+// the same with the norm of conj(y) * x known (see so3_log_fast_n)
+template <class T> UKFB_DEV void rot_minus_n(const T (&qx)[4], const T (&qy)[4], T nrm, T (&r)[3]) {
+    const T oc[4] = {-qy[0], -qy[1], -qy[2], qy[3]};
+    T d[4];
+    quat_mul(oc, qx, d);
+    so3_log_fast_n(d, nrm, r);
 }
 
 // process models with the fast exp (same statements as PoseM/OrientM::process)
@@ -360,7 +397,7 @@ template <class T, class M, bool DO_PREDICT, bool DO_UPDATE>
 __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
-    constexpr int LS = LY::LS, WS = LY::WS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
+    constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
     constexpr int G = 16, FPW = 4, EPL = (PK + G - 1) / G;
     static_assert(D + 1 <= G && S <= G, "a filter must fit one DPP row");
 
@@ -372,12 +409,13 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     const int64_t fc = fvalid ? f : (a.n - 1);
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC;
-    T* DXT = base + LY::DXT;
+    T* TAB = base + LY::TNL;
     T* PKS = base + LY::PKS;
+    T* LAF = base + LY::LAF;
+    T* WT = base + LY::WT;
     T* MUS = base + LY::MUS;
     T* ROT = base + LY::ROT;
     T* ZQ = base + LY::ZQ;
-    T* WK = base + LY::WK;
     T* DUMP = base + LY::DUM;
     const bool has_pair = l < D;       // lane owns the sigma pair of column l
     const bool has_ctr = l == D;       // lane owns the centre point
@@ -490,12 +528,17 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     if constexpr (DO_PREDICT) {
         if (__any(do_p)) {
             UKFB_MARK("p_chol");
+            constexpr int NL = LY::NL, ST = LY::ST, TRIP = LY::TRIP;
+            // stored index of a nonlinear Euclidean tangent component t (t outside [RT, RT + 3))
+            constexpr auto st_of = [](int t) constexpr { return t < MT<M>::RT ? t : t + 1; };
             T xp[S], xm[S], ref[S];
             bool ok;
+            T qn2;   // |q|^2 of the mean's orientation = norm of every conj(a) * b between sigma-point orientations
             {
                 T mu_r[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
+                qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
                 // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose
                 // acceleration branch does not rotate its noise (wave-uniform skip)
                 if (M::MODEL != 0 || !__all(pin.use_acc)) {
@@ -516,6 +559,13 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 UKFB_MARK("p_sigma");
                 T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
+                {   // affine rows of this lane's column, scaled by the model's diagonal factor, for the cross block;
+                    // lanes without a column hold zeros and fill the table's zero row
+                    T* lrow = LAF + ((l < D) ? l : D) * ST;
+#pragma unroll
+                    for (int c = NL; c < D; ++c) lrow[c - NL] = (M::MODEL == 0) ? col[c] : col[c] * MT<M>::aff_scale(c, pin);
+                    TAB[(l < ST) ? (N * ST + l) : (LY::DUM - LY::TNL)] = T(0);   // zero row of the delta table
+                }
                 sigma_pair<T, M>(mu_r, col, xp, xm);
             }
             UKFB_MARK("p_process");
@@ -526,43 +576,43 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             process_fast((M*)nullptr, xm, pin);
             sfence();
             UKFB_MARK("p_mean1");
-            // propagated centre point (lane D): every lane starts the mean from it
+            // Propagated centre point (lane D): every lane starts the mean from it.  The affine components
+            // (tangent >= NL) of the sigma points are centre +- scale * L[c][l] exactly, so their mean IS the centre
+            // (ukfom's iteration finds a correction at rounding level) and their deltas are the signed factor rows.
 #pragma unroll
             for (int s = 0; s < S; ++s) ref[s] = row_bcast<D>(xp[s]);
             const bool has_p = has_pair || has_ctr, has_m = has_pair;
             const T wp = has_p ? T(1) : T(0), wm = has_m ? T(1) : T(0);
 
-            // ---- ukfom meanSigmaPoints, first iteration over the whole tangent (reference = centre)
+            // ---- ukfom meanSigmaPoints, first iteration over the nonlinear components (reference = centre)
             sfence();
             T n2 = T(0);
             {
-                T loc[D];
+                T loc[NL];
                 {
                     const T qr[4] = {ref[Q], ref[Q + 1], ref[Q + 2], ref[Q + 3]};
                     const T qp[4] = {xp[Q], xp[Q + 1], xp[Q + 2], xp[Q + 3]};
                     const T qm[4] = {xm[Q], xm[Q + 1], xm[Q + 2], xm[Q + 3]};
                     T rp[3], rm[3];
-                    rot_minus(qp, qr, rp);
-                    rot_minus(qm, qr, rm);
+                    rot_minus_n(qp, qr, qn2, rp);
+                    rot_minus_n(qm, qr, qn2, rm);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) loc[RT + k] = fma(wm, rm[k], wp * rp[k]);
                 }
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (s < Q) loc[s] = fma(wm, xm[s] - ref[s], wp * (xp[s] - ref[s]));
-                    else if (s >= Q + 4) loc[s - 1] = fma(wm, xm[s] - ref[s], wp * (xp[s] - ref[s]));
-                }
-                T md[D];
+                for (int t = 0; t < NL; ++t)
+                    if (t < RT || t >= RT + 3) loc[t] = fma(wm, xm[st_of(t)] - ref[st_of(t)], wp * (xp[st_of(t)] - ref[st_of(t)]));
+                T md[NL];
                 if constexpr (sizeof(T) == 8) {
-                    // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) table region:
+                    // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) factor region:
                     // lane c sums component c over the 16 lanes and publishes the mean
-                    constexpr int TS = 18;   // row stride: b128 rows of lanes 0..D-1 fall on distinct banks
-                    static_assert(D * TS + D <= N * LS, "transposition buffer must fit the table region");
-                    T* TB = DXT;
+                    constexpr int TS = 18;   // row stride: b128 rows of lanes 0..NL-1 fall on distinct banks
+                    static_assert(NL * TS + NL <= D * LS, "transposition buffer must fit the factor region");
+                    T* TB = Lc;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) TB[c * TS + l] = loc[c];
+                    for (int c = 0; c < NL; ++c) TB[c * TS + l] = loc[c];
                     wsync();
-                    const int cl = (l < D) ? l : (D - 1);
+                    const int cl = (l < NL) ? l : (NL - 1);
                     T part[16];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) part[j] = TB[cl * TS + j];
@@ -570,16 +620,16 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
                         for (int j = 0; j < w; ++j) part[j] += part[j + w];
-                    TB[D * TS + cl] = part[0] * (T(1) / T(N));
+                    TB[NL * TS + cl] = part[0] * (T(1) / T(N));
                     wsync();
 #pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        md[c] = TB[D * TS + c];
+                    for (int c = 0; c < NL; ++c) {
+                        md[c] = TB[NL * TS + c];
                         n2 += md[c] * md[c];
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < D; ++c) {
+                    for (int c = 0; c < NL; ++c) {
                         md[c] = row_allreduce(loc[c]) * (T(1) / T(N));
                         n2 += md[c] * md[c];
                     }
@@ -592,27 +642,30 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     so3_exp_fast(v, T(1), e);
                     quat_mul(qr, e, r);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (s < Q) ref[s] += md[s];
-                        else if (s >= Q + 4) ref[s] += md[s - 1];
-                        else ref[s] = r[s - Q];
-                    }
+                    for (int t = 0; t < NL; ++t)
+                        if (t < RT || t >= RT + 3) ref[st_of(t)] += md[t];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ref[Q + k] = r[k];
                 }
             }
             UKFB_MARK("p_delta_e");
-            // Euclidean part of the mean is final: write those delta columns now and drop the registers
-            wsync();  // every lane is done with the factor columns (they alias the table)
+            // Euclidean part of the mean is final: write those delta columns now and drop the registers.
+            // Delta table rows 0..D: +column l / centre, rows D+1..2D: -column l; W row l = (delta+ - delta-) / 2
+            // (lanes without a column carry the centre twice: their W row is the table's zero row).
+            wsync();  // every lane is done with the transposition buffer (it aliases the table)
+            T* const rowp = has_p ? (TAB + l * ST) : DUMP;
+            T* const rowm = has_m ? (TAB + (D + 1 + l) * ST) : DUMP;
+            T* const roww = WT + ((l < D) ? l : D) * ST;
             {
-                // rows 0..D: +column l / centre, rows D+1..2D: -column l (lane stride LS: see Layout16::LS)
-                T* rowp = has_p ? (DXT + l * LS) : DUMP;
-                T* rowm = has_m ? (DXT + (D + 1 + l) * LS) : DUMP;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (s < Q) { rowp[s] = xp[s] - ref[s]; rowm[s] = xm[s] - ref[s]; }
-                    else if (s >= Q + 4) { rowp[s - 1] = xp[s] - ref[s]; rowm[s - 1] = xm[s] - ref[s]; }
-                }
+                for (int t = 0; t < NL; ++t)
+                    if (t < RT || t >= RT + 3) {
+                        rowp[t] = xp[st_of(t)] - ref[st_of(t)];
+                        rowm[t] = xm[st_of(t)] - ref[st_of(t)];
+                        roww[t] = T(0.5) * (xp[st_of(t)] - xm[st_of(t)]);
+                    }
             }
-            {   // mean staging: Euclidean part now, quaternion after the loop (lane 0)
+            {   // mean staging: everything but the quaternion now, the quaternion after the loop (lane 0)
                 T* dst = (pc && l == 0) ? MUS : DUMP;
 #pragma unroll
                 for (int s = 0; s < S; ++s)
@@ -631,8 +684,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
                 while (__any(active)) {
                     T rp[3], rm[3], mr[3];
-                    rot_minus(qp, qr, rp);
-                    rot_minus(qm, qr, rm);
+                    rot_minus_n(qp, qr, qn2, rp);
+                    rot_minus_n(qm, qr, qn2, rm);
                     T m2 = T(0);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) mr[k] = fma(wm, rm[k], wp * rp[k]);
@@ -657,110 +710,133 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             UKFB_MARK("p_delta_r");
             {   // rotation deltas to the final mean; quaternion of the mean
                 T rp[3], rm[3];
-                rot_minus(qp, qr, rp);
-                rot_minus(qm, qr, rm);
-                // rows 0..D: +column l / centre, rows D+1..2D: -column l (lane stride LS: see Layout16::LS)
-                T* rowp = has_p ? (DXT + l * LS) : DUMP;
-                T* rowm = has_m ? (DXT + (D + 1 + l) * LS) : DUMP;
+                rot_minus_n(qp, qr, qn2, rp);
+                rot_minus_n(qm, qr, qn2, rm);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { rowp[RT + k] = rp[k]; rowm[RT + k] = rm[k]; }
+                for (int k = 0; k < 3; ++k) {
+                    rowp[RT + k] = rp[k];
+                    rowm[RT + k] = rm[k];
+                    roww[RT + k] = T(0.5) * (rp[k] - rm[k]);
+                }
                 T* dst = (pc && l == 0) ? MUS : DUMP;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dst[Q + k] = qr[k];
             }
             wsync();
             UKFB_MARK("p_cov");
-            // ---- covariance tiles: lane -> (r0, c0) of a TR x TC block with c0 <= r0 + TR - 1
-            int r0 = -1, c0 = 0;
-            {
-                int cnt = 0;
-#pragma unroll
-                for (int p = 0; p < (D + TR - 1) / TR; ++p) {
-#pragma unroll
-                    for (int qq = 0; qq < (D + TC - 1) / TC; ++qq) {
-                        if (TC * qq <= TR * p + TR - 1) {
-                            r0 = (cnt == l) ? TR * p : r0;
-                            c0 = (cnt == l) ? TC * qq : c0;
-                            ++cnt;
-                        }
-                    }
-                }
-            }
-            const bool tile_ok = r0 >= 0;
-            const int tr0 = tile_ok ? r0 : 0;
+            // ---- covariance.  With d = delta table (N rows, NL columns), W as above, A = scaled affine factor rows:
+            //   nonlinear block   Sigma'[a][b] = 1/2 sum_i d_i[a] d_i[b]                      (a, b < NL)
+            //   cross block       Sigma'[c][a] = sum_l A_l[c] W_l[a]                           (c >= NL > a)
+            //   affine block      Sigma'[c][e] = s_c s_e Sigma[c][e]                            (c, e >= NL; L L^T = Sigma)
+            // each plus the shaped process noise.  Lane -> one TR x TC tile (MT<M>::TILE_R / TILE_C): a tile of the
+            // nonlinear block is shared by two lanes (rows 0..D and D+1..N of the table, N = zero row), a tile of the
+            // cross block belongs to one lane (rows 0..D of A and W, D = zero row): TRIP = D + 1 iterations for all.
+            const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
+            const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
+            const bool is_cross = R0 >= NL;
+            const int half = is_cross ? 0 : (lw & 1);
+            const T* pr = is_cross ? (LAF + (R0 - NL)) : (TAB + half * (TRIP * ST) + R0);
+            const T* pc_ = is_cross ? (WT + C0) : (TAB + half * (TRIP * ST) + C0);
             // shaped process noise of this lane's tile: with a plain table (Pose acceleration branch) it is
             // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
             // (it would hold 2 x TR x TC products in flight across the loop)
             constexpr bool NZ_EARLY = (M::MODEL == 0);
-            T acc[TR][TC], nz[TR][TC];
+            constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
+            const T* Rn = a.Rn + fc * a.Rn_stride;
+            const T* Ra = a.Racc + fc * a.Rn_stride;
+            const bool all_acc = NZ_EARLY && __all(pin.use_acc);
+            // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle
+            int ar[AEL], ac[AEL];
+            bool av[AEL];
+#pragma unroll
+            for (int t = 0; t < AEL; ++t) {
+                const int e = l + G * t;
+                av[t] = e < NAB;
+                int rr_ = 0;
+#pragma unroll
+                for (int r = 1; r < D - NL; ++r) rr_ += (e >= r * (r + 1) / 2) ? 1 : 0;
+                rr_ = av[t] ? rr_ : 0;
+                ar[t] = NL + rr_;
+                ac[t] = NL + (av[t] ? (e - rr_ * (rr_ + 1) / 2) : 0);
+            }
+            T acc[TR][TC], nz[TR][TC], anz[AEL];
             {
-                const T* Rn = a.Rn + fc * a.Rn_stride;
-                const T* Ra = a.Racc + fc * a.Rn_stride;
-                const bool all_acc = NZ_EARLY && __all(pin.use_acc);
 #pragma unroll
                 for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                     for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = nz[i2][j2] = T(0);
+#pragma unroll
+                for (int t = 0; t < AEL; ++t) anz[t] = T(0);
                 if (all_acc) {   // wave-uniform: plain table reads, all in flight together
 #pragma unroll
                     for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                         for (int j2 = 0; j2 < TC; ++j2) {
-                            const int r = tr0 + i2, c = c0 + j2;
+                            const int r = R0 + i2, c = C0 + j2;
                             const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
                             nz[i2][j2] = Ra[rc * D + cc];
                         }
+#pragma unroll
+                    for (int t = 0; t < AEL; ++t) anz[t] = Ra[ar[t] * D + ac[t]];
                 } else if (NZ_EARLY) {
 #pragma unroll
                     for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                         for (int j2 = 0; j2 < TC; ++j2) {
-                            const int r = tr0 + i2, c = c0 + j2;
+                            const int r = R0 + i2, c = C0 + j2;
                             const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
                             nz[i2][j2] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
                         }
+#pragma unroll
+                    for (int t = 0; t < AEL; ++t) anz[t] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, ar[t], ac[t]);
                 }
             }
-#pragma unroll 5
-            for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int i = 0; i < TRIP; ++i) {
                 T vr[TR], vc[TC];
 #pragma unroll
-                for (int k = 0; k < TR; ++k) vr[k] = DXT[i * LS + tr0 + k];
+                for (int k = 0; k < TR; ++k) vr[k] = pr[i * ST + k];
 #pragma unroll
-                for (int k = 0; k < TC; ++k) vc[k] = DXT[i * LS + c0 + k];
+                for (int k = 0; k < TC; ++k) vc[k] = pc_[i * ST + k];
 #pragma unroll
                 for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                     for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = fma(vr[i2], vc[j2], acc[i2][j2]);
             }
-            wsync();  // table reads done before the staging area (inside the table) is rewritten
             p_commit = pc;
             st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
             st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
+            {
+                // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
+                // (weight 0: its neighbour's accumulators are finite sums of the same filter)
+                const T wsum = is_cross ? T(0) : T(1);
+                const T fac = is_cross ? T(1) : T(0.5);   // the affine factor rows in LAF are already scaled
+                const bool writer = p_commit && (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
 #pragma unroll
-            for (int i2 = 0; i2 < TR; ++i2)
+                for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                for (int j2 = 0; j2 < TC; ++j2) {
-                    const int r = tr0 + i2, c = c0 + j2;
-                    const bool w = p_commit && tile_ok && r < D && c <= r;
-                    const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
-                    const T nv = NZ_EARLY ? nz[i2][j2]
-                                          : process_noise_entry16<T, M>(a.Rn + fc * a.Rn_stride, a.Racc + fc * a.Rn_stride, ROT, a, pin, rc, cc);
-                    PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = fma(T(0.5), acc[i2][j2], nv);
+                    for (int j2 = 0; j2 < TC; ++j2) {
+                        const int r = R0 + i2, c = C0 + j2;
+                        const bool w = writer && r < D && c <= r;
+                        const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+                        const T nv = NZ_EARLY ? nz[i2][j2] : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
+                        const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
+                        PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = fma(fac, tot, nv);
+                    }
+                // affine block in place: the old entries are still staged
+#pragma unroll
+                for (int t = 0; t < AEL; ++t) {
+                    const int idx = ar[t] * (ar[t] + 1) / 2 + ac[t];
+                    T old = PKS[idx];
+                    keep(old);
+                    const T nv = NZ_EARLY ? anz[t] : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, ar[t], ac[t]);
+                    const T ss = (M::MODEL == 0) ? T(1) : MT<M>::aff_scale(ar[t], pin) * MT<M>::aff_scale(ac[t], pin);
+                    PKS[(p_commit && av[t]) ? idx : (LY::DUM - LY::PKS)] = fma(ss, old, nv);
                 }
-            UKFB_MARK("p_end");
-            // a gated / failed predict must leave the ORIGINAL state for the update and the commit:
-            // re-stage it from HBM (rare path, wave-uniform guard)
-            if (__any(fvalid && !p_commit)) {
-#pragma unroll
-                for (int t = 0; t < EPL; ++t) {
-                    const int e = l + G * t;
-                    const T v = a.cov[fc * PK + ((e < PK) ? e : (PK - 1))];
-                    PKS[(!p_commit && e < PK) ? e : (LY::DUM - LY::PKS)] = v;
-                }
-                const T v = a.mu[fc * S + ((l < S) ? l : (S - 1))];
-                MUS[(!p_commit && l < S) ? l : (LY::DUM - LY::MUS)] = v;
             }
+            UKFB_MARK("p_end");
+            // a gated / failed predict leaves the staged state as it was: every store to MUS / PKS above is
+            // predicated on this filter's commit
             wsync();
         }
     }
@@ -786,7 +862,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             // Measurement statistics: S (innovation covariance), cx (row l of Sigma_xz), innovation.
             bool ok1 = true, zconv = true;
             T Sm[9], cx[3], innov[3];
-            T* wrow = has_pair ? (WK + l * WS) : DUMP;
             const int la = has_pair ? l : (D - 1);
             if (MT<M>::HAS_EUCLID_MEAS) {
                 // Sub-state selections (PoseUKF.cpp:7-26,35-69) are LINEAR in the tangent, and the unscented
@@ -1041,8 +1116,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 so3_exp_fast(v0, T(1), e0);
                 so3_exp_fast(vp, T(1), ep);
                 so3_exp_fast(vm, T(1), em);
-                rot_minus(ep, e0, rp);   // log(conj(q e0) (q e+)) = log(conj(e0) e+)
-                rot_minus(em, e0, rm);
+                rot_minus_n(ep, e0, T(1), rp);   // log(conj(q e0) (q e+)) = log(conj(e0) e+): unit quaternions
+                rot_minus_n(em, e0, T(1), rm);
             }
             sfence();
             UKFB_MARK("u_rr_cross");
@@ -1073,10 +1148,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     fmac_bcast<j>(cr[2], w[2], v);
                 });
             }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wrow[k] = cr[k];
-            wsync();
-
             st |= (do_u && (!ok1 || (accept && !ok2))) ? ST_ERR_CHOLESKY : 0u;
             st |= (do_u && ok1 && !accept) ? ST_REJECTED_GATE : 0u;
             st |= (do_u && ok1 && !zconv) ? ST_WARN_MEAN_NOCONV : 0u;
@@ -1084,29 +1155,38 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 
             sfence();
             UKFB_MARK("u_assemble");
-            // ---- assemble row l of the resampled covariance
+            // ---- resampled covariance into the staging area, in three ordered passes of plain stores (one
+            // wavefront: LDS stores retire in program order, later passes overwrite earlier ones):
+            //   1. row l of the downdated Sigma' (the Euclidean block IS the resampled block, see the header note)
+            //   2. the cross terms of row l with the three rotation columns, stored at the symmetric position
+            //      (max, min) so no exchange between lanes is needed
+            //   3. the rotation-rotation block, identical on every lane after the all-reduce (lane 0 stores it)
             {
-                const bool lrot = (l >= RT) && (l < RT + 3);
-                const int li = (l - RT) < 0 ? 0 : ((l - RT) > 2 ? 2 : (l - RT));
+                const bool wl = u_commit && has_pair;
+                // Pass 1 stores the WHOLE row (b = D-1 .. 0) at rowbase + b with no per-entry predicate: the entries
+                // beyond the diagonal spill into the slots of later rows, and every such slot (r, c) is rewritten
+                // afterwards by its owner, because a spill from row l < r lands there at step b' = c + (rowbase(r) -
+                // rowbase(l)) > c, i.e. earlier in this descending loop.  The last row has nothing beyond its diagonal.
+                // (The stores of one lane never alias each other, so the compiler would be free to reorder or pair
+                // them; the order that matters is between LANES, hence the compiler fence after every store.)
+                T* rowdst = wl ? (PKS + l * (l + 1) / 2) : DUMP;
 #pragma unroll
-                for (int b = 0; b < D; ++b) {
-                    const bool brot = (b >= RT) && (b < RT + 3);
-                    T v;
-                    if (brot) {   // compile-time per b
-                        const int bi = b - RT;
-                        const int hi = li > bi ? li : bi, lo = li > bi ? bi : li;
-                        T rrv = T(0);
-#pragma unroll
-                        for (int s6 = 0; s6 < 6; ++s6) rrv = (hi * (hi + 1) / 2 + lo == s6) ? rr[s6] : rrv;
-                        v = lrot ? rrv : cr[bi];
-                    } else {
-                        T other = WK[b * WS + li];   // cross term computed by lane b for rotation column li
-                        keep(other);
-                        v = lrot ? other : srow2[b];
-                    }
-                    const bool w = u_commit && has_pair && b <= l;
-                    PKS[w ? (l * (l + 1) / 2 + b) : (LY::DUM - LY::PKS)] = v;
+                for (int b = D - 1; b >= 0; --b) {
+                    rowdst[b] = srow2[b];
+                    asm volatile("" ::: "memory");
                 }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int hi = l > RT + k ? l : RT + k, lo = l > RT + k ? RT + k : l;
+                    PKS[wl ? (hi * (hi + 1) / 2 + lo) : (LY::DUM - LY::PKS)] = cr[k];
+                }
+                asm volatile("" ::: "memory");
+                const bool w0 = u_commit && l == 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c)
+                        PKS[w0 ? ((RT + r) * (RT + r + 1) / 2 + RT + c) : (LY::DUM - LY::PKS)] = rr[r * (r + 1) / 2 + c];
             }
             sfence();
             UKFB_MARK("u_mean");

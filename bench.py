@@ -45,6 +45,7 @@ N_SIMD = 1024                      # 256 CUs x 4 SIMDs
 N_RING = 4                         # input sets the steps cycle through
 SUSTAINED_STEPS = 500
 BURST_STEPS = 20
+RECENT_CYCLES = 16                 # window of the second in-run parity check
 TOL = {"f64": 1e-9, "f32": 1e-4}   # north_star
 
 
@@ -180,20 +181,24 @@ def cpu_baseline(args):
                       f"{e_all:.2f} s"}
 
 
-def parity_check(args, spe, eng, first, sample, cycles, orient):
-    """GPU state of filters [first, first+sample) of this rank against an oracle replay of the SAME launches:
-    `cycles` fused cycles over the input ring, starting from the synthetic initial state."""
+def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):
+    """GPU state of filters [first, first+sample) of this rank against an oracle replay of the SAME launches.
+    start = None: all `cycles` fused cycles of this run, from the synthetic initial state.
+    start = (mu, cov, k0): the last cycles only, from a GPU state downloaded k0 cycles into the run (the fp32
+    engine drifts from an fp64 replay over hundreds of cycles of a filter whose orientation is unobserved; the
+    recent window shows the per-cycle agreement in the regime the timed region ran in)."""
     import numpy as np
     from oracle import capi
     sy = spe.synth
     f32 = (lambda x: x.astype(np.float32).astype(np.float64)) if args.precision == "f32" else (lambda x: x)
     threads = max(1, min(_threads_available(), capi.max_threads()))
     m_g, c_g, _ = eng.state(0, sample)
+    k0 = 0 if start is None else start[2]
     if orient:
         mu, cov = sy.orient_initial(sample, first=first)
         ring = [sy.orient_cycle_inputs(sample, k, mu[:, :4], first=first) for k in range(N_RING)]
-        m_o, c_o = f32(mu), f32(cov)
-        for k in range(cycles):
+        m_o, c_o = (f32(mu), f32(cov)) if start is None else (start[0], start[1])
+        for k in range(k0, cycles):
             gyro, acc, z, Q = ring[k % N_RING]
             m_o, c_o, _ = capi.orient_predict(m_o, c_o, sy.orient_process_noise(), f32(acc), f32(gyro), sy.ORIENT_TAU,
                                               sy.ORIENT_TAU, eng.earth_rotation, DT, threads=threads)
@@ -211,16 +216,18 @@ def parity_check(args, spe, eng, first, sample, cycles, orient):
             ring.append((acc, z, Q, models))
         R = sy.pose_default_process_noise()
         acc_cov = 0.01 * np.eye(3)
-        m_o, c_o = f32(mu), f32(cov)
-        for k in range(cycles):
+        m_o, c_o = (f32(mu), f32(cov)) if start is None else (start[0], start[1])
+        for k in range(k0, cycles):
             acc, z, Q, models = ring[k % N_RING]
             m_o, c_o, _ = capi.pose_predict(m_o, c_o, R, f32(acc), acc_cov, DT, threads=threads)
             m_o, c_o, _ = capi.pose_update(m_o, c_o, models, f32(z), f32(Q), threads=threads)
     em, ec = float(np.abs(m_g - m_o).max()), float(np.abs(c_g - c_o).max())
     tol = TOL[args.precision]
+    what = (f"after {cycles} fused cycles of this run (pre-roll + warm-up + timed)" if start is None else
+            f"cycles {k0}..{cycles - 1} of this run, from the GPU state downloaded before them")
     return {"max_abs_mu": em, "max_abs_cov": ec, "tol": tol, "ok": bool(em <= tol and ec <= tol),
-            "sample": f"filters {first}..{first + sample - 1} after {cycles} fused cycles of this run (pre-roll + warm-up + "
-                      f"timed), GPU state vs oracle/ukf_oracle.hpp (fp64) replay of the same input ring"}
+            "sample": f"filters {first}..{first + sample - 1} {what}, GPU state vs oracle/ukf_oracle.hpp (fp64) replay "
+                      f"of the same input ring"}
 
 
 def load_profile_entry(name, kernel_name, filters_per_launch):
@@ -380,6 +387,17 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     fence()
+    # snapshot of the warmed-up state (device to device) so that the extra kernel-time regions below start where
+    # the timed region started: the headline workload is not stationary (the unobserved orientation covariance
+    # grows with every cycle and moves the SO(3) maps onto their wide-angle paths)
+    mu_ptr, cov_ptr, _ = eng.device_views()
+    ts_ = "<f8" if prec == spe.F64 else "<f4"
+    mu_view = torch.as_tensor(_DevArray(mu_ptr, (per, S), ts_), device=dev)
+    cov_view = torch.as_tensor(_DevArray(cov_ptr, (per, eng.PK), ts_), device=dev)
+    snap = None
+    if not args.no_extra_regions:
+        snap = (mu_view.clone(), cov_view.clone(), done[0])
+        torch.cuda.synchronize()
     eng.timer_begin()           # HIP events on the stream the kernel is launched on
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -396,16 +414,21 @@ def run_rank(args):
     status_or = eng.status_summary()
 
     # ---- in-run parity on rank 0's first filters (before anything else advances the state)
-    parity = None
+    parity = parity_recent = None
     if rank == 0 and not args.no_parity:
         sample = min(args.parity_sample, per)
         parity = parity_check(args, spe, eng, first, sample, done[0], orient)
+        m0, c0, _ = eng.state(0, sample)
+        k0 = done[0]
+        for _ in range(RECENT_CYCLES):
+            step()
+        eng.sync()
+        parity_recent = parity_check(args, spe, eng, first, sample, done[0], orient, start=(m0, c0, k0))
 
     # ---- result gather over RCCL/xGMI (outside the timed region; means only)
     gather_ms = None
     if dist is not None:
-        mu_ptr, _, _ = eng.device_views()
-        mu_local = torch.as_tensor(_DevArray(mu_ptr, (per, S), "<f8" if prec == spe.F64 else "<f4"), device=dev)
+        mu_local = mu_view
         if args.backend != "nccl":
             mu_local = mu_local.cpu()
         fence()
@@ -420,8 +443,16 @@ def run_rank(args):
     kernel_ms = kernel_ms_total / args.steps
     sustained_ms = burst_ms = None
     if not args.no_extra_regions:
-        sustained_ms = kernel_ms if args.steps >= SUSTAINED_STEPS else kernel_region(SUSTAINED_STEPS)
-        eng.sync()
+        def restore():
+            eng.sync()
+            mu_view.copy_(snap[0]); cov_view.copy_(snap[1])
+            torch.cuda.synchronize()
+            done[0] = snap[2]
+        sustained_ms = kernel_ms
+        if args.steps < SUSTAINED_STEPS:
+            restore()
+            sustained_ms = kernel_region(SUSTAINED_STEPS)
+        restore()
         time.sleep(1.0)    # let the clocks recover
         burst_ms = kernel_region(BURST_STEPS)
         fence()
@@ -487,6 +518,7 @@ def run_rank(args):
             "ms_per_step_rank_min": rank_lo, "ms_per_step_rank_max": rank_hi,
             "gather_ms": gather_ms,
             "parity": parity,
+            "parity_recent": parity_recent,
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "pose":
             out["cpu_baseline"] = cpu_baseline(args)

@@ -176,18 +176,19 @@ template <class T, class M> struct Layout16 {
     static constexpr int al(int x) { return (x + VEC - 1) / VEC * VEC; }
     static constexpr int PKP = al(PK);
     // Prediction tables.  Only the NL = 6 leading tangent components are nonlinear in the state for both models
-    // (MT<M>), so the delta table holds 6 columns; the affine rows of the factor and the half differences
-    // W_l = (delta+_l - delta-_l) / 2 serve the cross block.  Row stride ST (6 / 7 scalars): lane-strided b64 / b32
-    // accesses of lanes 0..15 fall on distinct banks, and D - NL <= ST.  Every table has one extra all-zero row so
-    // that all lanes run the same trip count D + 1 (N + 1 = 2 (D + 1) rows of deltas in two halves).
+    // (MT<M>), so the delta table holds 6 columns.  It stores the sigma-point deltas as half sums and half differences,
+    //   rows 0..D-1: U_l = (delta+_l + delta-_l) / 2,  row D: delta_0 / sqrt(2),  rows D+1..2D: W_l = (delta+_l - delta-_l) / 2,
+    // because 1/2 sum_i delta_i delta_i^T = sum over these rows of row row^T, and the W rows are at the same time the
+    // left factor of the cross block (with the affine rows of the factor, LAF).  Row stride ST (6 / 7 scalars):
+    // lane-strided b64 / b32 accesses of lanes 0..15 fall on distinct banks, and D - NL <= ST.  Row N of the table and
+    // row D of LAF are all-zero, so every lane runs the same trip count D + 1 (the table has 2 (D + 1) rows).
     static constexpr int NL = 6, ST = (D == 12) ? 6 : 7, TRIP = D + 1;
     static constexpr int LC = 0;                            // D*LS : unscaled factor columns
     // delta table rows 0..N-1 alias the factor (dead once every lane holds its column); its zero row lies behind it
     static constexpr int TNL = (D * LS > N * ST) ? (D * LS - N * ST) : 0;
     static constexpr int PKS = al(TNL + (N + 1) * ST);      // PKP  : packed covariance staging (survives the prediction)
     static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor
-    static constexpr int WT = LAF + al((D + 1) * ST);       // (D+1)*ST : row l = W_l
-    static constexpr int MISC = WT + al((D + 1) * ST);
+    static constexpr int MISC = LAF + al((D + 1) * ST);
     static constexpr int MUS = MISC;                        // 16 : mean staging
     static constexpr int ROT = MISC + 16;                   // 12 : rotation matrix of the mean
     static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
@@ -412,7 +413,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     T* TAB = base + LY::TNL;
     T* PKS = base + LY::PKS;
     T* LAF = base + LY::LAF;
-    T* WT = base + LY::WT;
     T* MUS = base + LY::MUS;
     T* ROT = base + LY::ROT;
     T* ZQ = base + LY::ZQ;
@@ -552,7 +552,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 T rs;
                 {
                     T arow[D];
+                    UKFB_MARK("p_chol_row");
                     load_row<T, D>(PKS, l, arow);
+                    UKFB_MARK("p_chol_fact");
                     rs = chol16<T, D, LS>(arow, Lc, l, ok);
                     wsync();
                 }
@@ -564,7 +566,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     T* lrow = LAF + ((l < D) ? l : D) * ST;
 #pragma unroll
                     for (int c = NL; c < D; ++c) lrow[c - NL] = (M::MODEL == 0) ? col[c] : col[c] * MT<M>::aff_scale(c, pin);
-                    TAB[(l < ST) ? (N * ST + l) : (LY::DUM - LY::TNL)] = T(0);   // zero row of the delta table
                 }
                 sigma_pair<T, M>(mu_r, col, xp, xm);
             }
@@ -650,18 +651,17 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             UKFB_MARK("p_delta_e");
             // Euclidean part of the mean is final: write those delta columns now and drop the registers.
-            // Delta table rows 0..D: +column l / centre, rows D+1..2D: -column l; W row l = (delta+ - delta-) / 2
-            // (lanes without a column carry the centre twice: their W row is the table's zero row).
             wsync();  // every lane is done with the transposition buffer (it aliases the table)
-            T* const rowp = has_p ? (TAB + l * ST) : DUMP;
-            T* const rowm = has_m ? (TAB + (D + 1 + l) * ST) : DUMP;
-            T* const roww = WT + ((l < D) ? l : D) * ST;
+            // rows 0..D (lane l <= D): U_l, the centre lane's row scaled by sqrt(1/2) (its U is delta_0);
+            // rows D+1..N: W_l, where the centre lane's W = 0 is the table's zero row
+            T* const rowu = has_p ? (TAB + l * ST) : DUMP;
+            T* const roww = has_p ? (TAB + (D + 1 + l) * ST) : DUMP;
+            const T fu = has_ctr ? T(0.70710678118654752440) : T(1);
             {
 #pragma unroll
                 for (int t = 0; t < NL; ++t)
                     if (t < RT || t >= RT + 3) {
-                        rowp[t] = xp[st_of(t)] - ref[st_of(t)];
-                        rowm[t] = xm[st_of(t)] - ref[st_of(t)];
+                        rowu[t] = fu * (T(0.5) * (xp[st_of(t)] + xm[st_of(t)]) - ref[st_of(t)]);
                         roww[t] = T(0.5) * (xp[st_of(t)] - xm[st_of(t)]);
                     }
             }
@@ -714,8 +714,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 rot_minus_n(qm, qr, qn2, rm);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    rowp[RT + k] = rp[k];
-                    rowm[RT + k] = rm[k];
+                    rowu[RT + k] = (fu * T(0.5)) * (rp[k] + rm[k]);
                     roww[RT + k] = T(0.5) * (rp[k] - rm[k]);
                 }
                 T* dst = (pc && l == 0) ? MUS : DUMP;
@@ -724,8 +723,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             wsync();
             UKFB_MARK("p_cov");
-            // ---- covariance.  With d = delta table (N rows, NL columns), W as above, A = scaled affine factor rows:
-            //   nonlinear block   Sigma'[a][b] = 1/2 sum_i d_i[a] d_i[b]                      (a, b < NL)
+            // ---- covariance.  With d = sigma-point deltas (NL columns), U / W as above, A = scaled affine factor rows:
+            //   nonlinear block   Sigma'[a][b] = 1/2 sum_i d_i[a] d_i[b] = sum over the table rows t of t[a] t[b]   (a, b < NL)
             //   cross block       Sigma'[c][a] = sum_l A_l[c] W_l[a]                           (c >= NL > a)
             //   affine block      Sigma'[c][e] = s_c s_e Sigma[c][e]                            (c, e >= NL; L L^T = Sigma)
             // each plus the shaped process noise.  Lane -> one TR x TC tile (MT<M>::TILE_R / TILE_C): a tile of the
@@ -736,7 +735,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             const bool is_cross = R0 >= NL;
             const int half = is_cross ? 0 : (lw & 1);
             const T* pr = is_cross ? (LAF + (R0 - NL)) : (TAB + half * (TRIP * ST) + R0);
-            const T* pc_ = is_cross ? (WT + C0) : (TAB + half * (TRIP * ST) + C0);
+            const T* pc_ = TAB + ((is_cross || half) ? (TRIP * ST) : 0) + C0;   // cross: the W rows
             // shaped process noise of this lane's tile: with a plain table (Pose acceleration branch) it is
             // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
             // (it would hold 2 x TR x TC products in flight across the loop)
@@ -810,7 +809,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
                 // (weight 0: its neighbour's accumulators are finite sums of the same filter)
                 const T wsum = is_cross ? T(0) : T(1);
-                const T fac = is_cross ? T(1) : T(0.5);   // the affine factor rows in LAF are already scaled
                 const bool writer = p_commit && (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
 #pragma unroll
                 for (int i2 = 0; i2 < TR; ++i2)
@@ -821,7 +819,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
                         const T nv = NZ_EARLY ? nz[i2][j2] : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
                         const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
-                        PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = fma(fac, tot, nv);
+                        PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
                     }
                 // affine block in place: the old entries are still staged
 #pragma unroll
@@ -868,6 +866,30 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 // transform of a linear map is exact: with Sigma = L L^T the sigma-point sums collapse to
                 //   zbar = mu[sel],  S = Sigma[sel][sel] + Q,  Sigma_xz = Sigma[:, sel]
                 // (the same identity applyDelta uses), so neither the factorisation nor the spread is needed.
+                // One model id for the whole launch (a kernel argument, i.e. scalar) that selects a full 3-vector --
+                // position, velocity or angular velocity: three consecutive tangent components from a scalar base,
+                // so every index below is scalar arithmetic and nothing needs a select.
+                const int mu_id = a.meas_uniform;
+                const bool uni3 = (a.meas == nullptr) && (mu_id == 0 || mu_id == 4 || mu_id == 8);
+                if (uni3) {
+                    const int tb = (mu_id == 0) ? 0 : ((mu_id == 4) ? 6 : 9);   // first tangent index
+                    const int sb = tb + ((tb >= Q) ? 1 : 0);                       // first stored index
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        innov[k] = zin[k] - MUS[sb + k];
+                        const int tk = tb + k;
+                        const int hi = la > tk ? la : tk, lo = la > tk ? tk : la;
+                        cx[k] = PKS[hi * (hi + 1) / 2 + lo];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) {
+                            const T sp = PKS[(tb + r) * (tb + r + 1) / 2 + tb + c];
+                            Sm[r * 3 + c] = sp + ZQ[3 + r * 3 + c];
+                            if (c < r) Sm[c * 3 + r] = sp + ZQ[3 + c * 3 + r];
+                        }
+                } else {
                 const unsigned long long sel[3] = {MT<M>::SEL0, MT<M>::SEL1, MT<M>::SEL2};
                 int ti[3];
                 bool used[3];
@@ -896,6 +918,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         keep(sq);
                         Sm[r * 3 + c] = (used[r] && used[c]) ? (sp + sq) : pad;
                     }
+                }
             }
             if (__any(need_q)) {
                 // Orientation-dependent models (PoseUKF.cpp:28-33, OrientationUKF.cpp:34-39): full sigma-point
@@ -1102,45 +1125,50 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             }
             sfence();
             UKFB_MARK("u_apply");
-            // ---- applyDelta: mu' = mu [+] delta; only the SO(3) rows/columns are re-sampled
-            T e0[4], rp[3], rm[3];
+            // ---- applyDelta: mu' = mu [+] delta; only the SO(3) rows/columns are re-sampled.  Only the first
+            // NC = RT + 3 columns of the (lower-triangular) factor have a rotation part, so there are 2 NC sigma
+            // points to push through exp / log: lane j < NC takes +column j, lane NC + j takes -column j.
+            constexpr int NC = RT + 3;
+            static_assert(2 * NC <= 16, "signed rotation columns must fit one DPP row");
+            T e0[4], rsg[3];
             {
-                const int lc = has_pair ? l : (D - 1);
+                const bool plus = l < NC, minus = (l >= NC) && (l < 2 * NC);
+                const int cidx = plus ? l : (minus ? (l - NC) : 0);
+                const T rs_m = dpp_mov<0x110 + NC>(rs2);                 // row_shr: lane l reads lane l - NC
+                const T wc = plus ? rs2 : (minus ? -rs_m : T(0));
                 T c3[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) c3[k] = Lc[lc * LS + RT + k] * (has_pair ? rs2 : T(0));
+                for (int k = 0; k < 3; ++k) c3[k] = Lc[cidx * LS + RT + k] * wc;
                 const T v0[3] = {d0[RT], d0[RT + 1], d0[RT + 2]};
-                const T vp[3] = {v0[0] + c3[0], v0[1] + c3[1], v0[2] + c3[2]};
-                const T vm[3] = {v0[0] - c3[0], v0[1] - c3[1], v0[2] - c3[2]};
-                T ep[4], em[4];
+                const T vs[3] = {v0[0] + c3[0], v0[1] + c3[1], v0[2] + c3[2]};
+                T es[4];
                 so3_exp_fast(v0, T(1), e0);
-                so3_exp_fast(vp, T(1), ep);
-                so3_exp_fast(vm, T(1), em);
-                rot_minus_n(ep, e0, T(1), rp);   // log(conj(q e0) (q e+)) = log(conj(e0) e+): unit quaternions
-                rot_minus_n(em, e0, T(1), rm);
+                so3_exp_fast(vs, T(1), es);
+                rot_minus_n(es, e0, T(1), rsg);   // log(conj(q e0) (q e+-)) = log(conj(e0) e+-): unit quaternions
             }
             sfence();
             UKFB_MARK("u_rr_cross");
-            // rotation-rotation block: 0.5 sum (r+ r+^T + r- r-^T)
+            // rotation-rotation block: 0.5 sum over the 2 NC signed points of r r^T (lanes without a point hold
+            // log(conj(e0) e0) = 0 up to rounding)
             T rr[6];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) rr[r * (r + 1) / 2 + c] = has_pair ? fma(rp[r], rp[c], rm[r] * rm[c]) : T(0);
+                for (int c = 0; c <= r; ++c) rr[r * (r + 1) / 2 + c] = rsg[r] * rsg[c];
             row_allreduce_n<T, 6>(rr);
 #pragma unroll
             for (int k = 0; k < 6; ++k) rr[k] *= T(0.5);
-            // cross terms of row l with the three rotation columns.  Columns past the rotation block have a zero
-            // rotation part (lower-triangular factor): r+ == r- bit for bit, their W row is zero.
+            // cross terms of row l with the three rotation columns: sum_j L'[l][j] W_j, W_j = (r+_j - r-_j) / 2 on lane j
             T cr[3] = {T(0), T(0), T(0)};
             {
                 T w[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    w[k] = T(0.5) * rs2 * (rp[k] - rm[k]);
+                    const T rmk = dpp_mov<0x100 + NC>(rsg[k]);           // row_shl: lane j reads lane j + NC
+                    w[k] = T(0.5) * rs2 * (rsg[k] - rmk);
                     dpp_hazard_fence(w[k]);
                 }
-                static_for<0, RT + 3>([&](auto jc) {
+                static_for<0, NC>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const T v = Lc[j * LS + la];   // zero for j > la
                     fmac_bcast<j>(cr[0], w[0], v);

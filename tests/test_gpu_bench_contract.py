@@ -11,9 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
+def run_bench(*args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
-                         timeout=600, cwd=ROOT)
+                         timeout=600, cwd=ROOT, env=e)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -33,16 +37,46 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert "traffic" in r   # PMC figure for the default workload, None for others
+    assert r["traffic"] is not None and r["traffic"] > 0            # PMC figure, scaled to this launch size
+    assert r["kernel_ms_per_launch"] > 0 and r["kernel_ms_per_launch_sustained"] > 0 and r["kernel_ms_per_launch_burst"] > 0
+    v = r["valu"]
+    assert v["bound"] == "valu-issue" and 0 < v["frac"] and v["valu_insts_per_wave"] > 0 and v["clock_mhz"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert c["single_core"]["cores"] == 1 and c["single_core"]["value"] > 0 and "march=native" in c["build"]
     assert d["value"] > 0 and abs(d["value"] - 16384 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6
-    assert d["status_or"] == 0
+    assert d["status_or"] == 0 and d["scaling"] == "strong" and d["rccl_ranks"] is None
+    assert d["config"]["filters"] == 16384 and d["config"]["filters_per_gpu"] == 16384
+    for key in ("parity", "parity_recent"):      # in-run parity against the oracle, fp64 tolerance of north_star
+        p = d[key]
+        assert p["tol"] == 1e-9 and p["ok"] is True and p["max_abs_mu"] <= 1e-9 and p["max_abs_cov"] <= 1e-9, p
 
 
 def test_bench_other_workloads_run():
     d = run_bench("--workload", "orient", "--precision", "f32", "--filters", "8192", "--steps", "3", "--warmup", "1",
                   "--no-cpu-baseline")
     assert d["dtype"] == "f32" and "OrientationState" in d["metric"] and d["status_or"] == 0
+    assert d["parity_recent"]["ok"] is True and d["parity_recent"]["tol"] == 1e-4
     d = run_bench("--workload", "pose-mixed", "--filters", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
-    assert d["value"] > 0
+    assert d["value"] > 0 and d["parity"]["ok"] is True
+
+
+def test_single_rank_rccl_rehearsal():
+    """The N > 1 code path (RCCL process group, barrier, all-reduce MAX, gather) with one rank on the one GPU."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = run_bench("--gpus", "1", "--filters", "16384", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra-regions",
+                  env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "UKFB_BENCH_FORCE_DIST": "1"})
+    assert d["rccl_ranks"] == 1 and d["backend"] == "nccl" and d["gather_ms"] is not None and d["status_or"] == 0
+    assert d["ms_per_step_rank_min"] <= d["ms_per_step_rank_max"]
+
+
+def test_two_self_launched_ranks_share_the_gpu_over_gloo():
+    """`python bench.py --gpus 2` with no wrapper: two child ranks, strong scaling (8 192 filters each), engine on
+    the same device, rank plumbing over gloo (a one-GPU box cannot form a 2-rank RCCL communicator)."""
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--filters", "16384", "--steps", "3", "--warmup", "1",
+                  "--no-cpu-baseline", "--no-extra-regions")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["filters_per_gpu"] == 8192
+    assert d["rccl_ranks"] is None and d["backend"] == "gloo" and d["gather_ms"] is not None and d["status_or"] == 0
+    assert d["value"] > 0 and d["parity"]["ok"] is True

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: per-configuration PMC passes for bench.py's roofline object (all five BASELINE configs).
+#   - FETCH_SIZE and WRITE_SIZE in separate passes, corrected with factors calibrated on the engine's own access
+#     pattern (tools/calib_traffic.hip; MI355X_MICROARCH.md: FETCH_SIZE halves wide coalesced reads on gfx950)
+#   - one SQ/GRBM pass: VALU wave-instructions, VALU busy quad-cycles, wave cycles, GRBM_GUI_ACTIVE (clock)
+#   - rocprofv3 --kernel-trace --stats of the default bench command
+# Output: gpurun_out/pmc_configs/{traffic_latest.json,pmc_latest.json,*_kernel_stats.csv,summary.txt}
+# usage: tools/pmc_configs.sh [tag]        (copy the json / csv files into profiles/ afterwards)
+set -u
+tag=${1:-r02}
+out=$PWD/gpurun_out/pmc_configs; rm -rf $out; mkdir -p $out
+export TMPDIR=/tmp
+hipcc -O2 --offload-arch=gfx950 tools/calib_traffic.hip -o $out/calib_traffic || exit 1
+for prec in f64 f32; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/calib_${prec}_$c -- $out/calib_traffic 1048576 $prec > $out/calib_${prec}_$c.json 2> $out/calib_${prec}_$c.err
+  done
+done
+B="--steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-extra-regions"
+cfg() {  # name, bench args
+  name=$1; shift
+  for pass in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    p=$(echo $pass | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/${name}_$p -- python3 bench.py $B "$@" > $out/${name}_$p.json 2> $out/${name}_$p.err
+    echo "$name $p rc=$?"
+  done
+}
+cfg headline_f64
+cfg headline_f32 --precision f32
+cfg cfg2 --filters 65536
+cfg cfg3 --filters 131072 --precision f32
+cfg cfg4 --workload orient --precision f32 --filters 4194304
+cfg cfg5 --workload pose-mixed --filters 262144
+# kernel stats of the default command (the driver's own invocation and the 500-step default)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions > $out/trace_default.json 2> $out/trace_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --precision f32 > $out/trace_f32.json 2> $out/trace_f32.err
+python3 tools/pmc_report.py $out $tag | tee $out/summary.txt

@@ -31,7 +31,7 @@ public:
     ukfb_engine* handle() { return engine; }
 
     /** initializeFilter for filters [first, first + count) */
-    void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov) { check(ukfb_initialize(engine, first, count, mu, cov)); }
+    virtual void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov) { check(ukfb_initialize(engine, first, count, mu, cov)); }
     /** getCurrentState for filters [first, first + count); cov may be NULL */
     void getCurrentStates(int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised = NULL) { check(ukfb_get_state(engine, first, count, mu, cov, initialised)); }
     void setProcessNoiseCovariance(const double* R) { check(ukfb_set_process_noise(engine, R)); }
@@ -100,6 +100,16 @@ public:
         : BatchUKF(UKFB_MODEL_ORIENT, precision, capacity, device)
     {
         check(ukfb_orient_set_params(engine, gyro_bias_tau, acc_bias_tau, earth_rotation));
+    }
+    /** initializeFilter plus the reference constructor's input latches (OrientationUKF.cpp:49-50):
+     *  rotation_rate.mu = 0 and acceleration.mu = (0, 0, initial gravity), so that a prediction before the first
+     *  IMU sample holds the velocity steady exactly as the scalar class does. */
+    virtual void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov)
+    {
+        BatchUKF::initializeFilters(first, count, mu, cov);
+        std::vector<double> gyro(static_cast<size_t>(count) * 3, 0.0), acc(static_cast<size_t>(count) * 3, 0.0);
+        for (int64_t i = 0; i < count; ++i) acc[static_cast<size_t>(i) * 3 + 2] = mu[static_cast<size_t>(i) * 14 + 13];
+        setInputs(first, count, gyro.data(), acc.data());
     }
     void setInputs(int64_t first, int64_t count, const double* gyro, const double* acc) { check(ukfb_orient_set_inputs(engine, first, count, gyro, acc)); }
     void getRotationRates(int64_t first, int64_t count, double* out) { check(ukfb_orient_get_rotation_rate(engine, first, count, out)); }

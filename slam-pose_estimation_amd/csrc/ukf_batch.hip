@@ -5,11 +5,14 @@
 // of the hot path is in ukf_kernel.hpp.  There is deliberately NO CPU fallback: without a HIP
 // device ukfb_create fails with UKFB_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
 #include <new>
+#include <thread>
+#include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
 
@@ -23,7 +26,7 @@ thread_local std::string g_last_error;
     do {                                                   \
         hipError_t _e = (expr);                            \
         if (_e != hipSuccess) {                            \
-            ukfb::set_error(#expr, _e);                    \
+            if (_e != hipErrorNotReady) ukfb::set_error(#expr, _e); /* NotReady: the bounded wait set the text */ \
             return UKFB_ERR_HIP;                           \
         }                                                  \
     } while (0)
@@ -136,24 +139,30 @@ int rebuild_racc(ukfb_engine* e) {
     if (e->model != UKFB_MODEL_POSE) return UKFB_OK;
     const int64_t nmat = e->Rn_per_filter ? e->cap : 1;
     const size_t dd = size_t(e->D) * e->D;
-    if (e->Racc) HIP_TRY(hipFree(e->Racc));
-    e->Racc = nullptr;
-    HIP_TRY(hipMalloc(&e->Racc, size_t(nmat) * dd * e->tsize));
-    void* ac = nullptr;
-    HIP_TRY(hipMalloc(&ac, 9 * e->tsize));
-    int rc = upload(e, ac, 0, e->acc_cov, 9);
+    // both buffers persist for the life of the engine (Racc grows once, when the noise becomes per-filter)
+    if (!e->Racc || e->Racc_mats < nmat) {
+        if (e->Racc) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipFree(e->Racc));
+        }
+        e->Racc = nullptr;
+        e->Racc_mats = 0;
+        HIP_TRY(hipMalloc(&e->Racc, size_t(nmat) * dd * e->tsize));
+        e->Racc_mats = nmat;
+    }
+    if (!e->acc_cov_dev) HIP_TRY(hipMalloc(&e->acc_cov_dev, 9 * sizeof(double)));
+    int rc = upload(e, e->acc_cov_dev, 0, e->acc_cov, 9);
     if (rc) return rc;
     const int64_t total = nmat * int64_t(dd);
     const int blocks = int((total + 255) / 256);
     if (e->prec == UKFB_F64)
         hipLaunchKernelGGL(build_racc_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->Rn),
-                           static_cast<double*>(e->Racc), nmat, e->D, static_cast<const double*>(ac));
+                           static_cast<double*>(e->Racc), nmat, e->D, static_cast<const double*>(e->acc_cov_dev));
     else
         hipLaunchKernelGGL(build_racc_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const float*>(e->Rn),
-                           static_cast<float*>(e->Racc), nmat, e->D, static_cast<const float*>(ac));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipFree(ac));
-    return UKFB_OK;
+                           static_cast<float*>(e->Racc), nmat, e->D, static_cast<const float*>(e->acc_cov_dev));
+    HIP_TRY(hipGetLastError());
+    return UKFB_OK;   // stream-ordered: the next launch on the engine's stream sees the new table
 }
 
 // BodyStateMeasurement::toRigidBodyState for a batch: one thread per output scalar (coalesced stores).
@@ -205,28 +214,34 @@ template <class T> __global__ void import_body_states_kernel(const T* in, int64_
     }
 }
 
+namespace {
+struct DevTmp {   // device scratch that is released on every exit path
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 template <class T> int export_body_states(ukfb_engine* e, int64_t first, int64_t count, double* out) {
-    T* dev = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), size_t(count) * 49 * sizeof(T)));
+    DevTmp dev;
+    HIP_TRY(hipMalloc(&dev.p, size_t(count) * 49 * sizeof(T)));
     const int blocks = int((count * 49 + 255) / 256);
     hipLaunchKernelGGL(export_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(e->mu),
-                       static_cast<const T*>(e->cov), first, count, dev);
-    int rc = download(e, dev, 0, out, size_t(count) * 49);
-    HIP_TRY(hipFree(dev));
-    return rc;
+                       static_cast<const T*>(e->cov), first, count, static_cast<T*>(dev.p));
+    HIP_TRY(hipGetLastError());
+    return download(e, dev.p, 0, out, size_t(count) * 49);
 }
 template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t count, const double* in) {
-    T* dev = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), size_t(count) * 49 * sizeof(T)));
-    int rc = upload(e, dev, 0, in, size_t(count) * 49);
+    DevTmp dev;
+    HIP_TRY(hipMalloc(&dev.p, size_t(count) * 49 * sizeof(T)));
+    int rc = upload(e, dev.p, 0, in, size_t(count) * 49);
     if (rc) return rc;
     const int blocks = int((count * 91 + 255) / 256);
-    hipLaunchKernelGGL(import_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(dev), first,
+    hipLaunchKernelGGL(import_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(dev.p), first,
                        count, static_cast<T*>(e->mu), static_cast<T*>(e->cov));
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
     HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipFree(dev));
     return UKFB_OK;
 }
 
@@ -297,18 +312,33 @@ void set_error(const char* what, hipError_t err) {
 
 // Waiting by polling: hipEventSynchronize / hipStreamSynchronize sleep on an interrupt and were measured to
 // wake up to ~55 ms late on a loaded host (1 run in 5), which is longer than the work being waited for.
-static hipError_t wait_stream_polling(hipStream_t s) {
+// The wait is bounded: after a short spin the poll backs off to 50 us sleeps, and gives up with hipErrorNotReady
+// after UKFB_WAIT_TIMEOUT_S seconds (default 120) so that a kernel that never finishes cannot pin a host core
+// forever; the caller reports UKFB_ERR_HIP with "timed out".
+static double wait_timeout_seconds() {
+    static const double t = [] {
+        const char* s = std::getenv("UKFB_WAIT_TIMEOUT_S");
+        const double v = s ? std::atof(s) : 0.0;
+        return v > 0.0 ? v : 120.0;
+    }();
+    return t;
+}
+template <class Query> static hipError_t wait_polling(Query&& query) {
     hipError_t r;
-    while ((r = hipStreamQuery(s)) == hipErrorNotReady) {
+    for (int spin = 0; spin < 20000; ++spin)
+        if ((r = query()) != hipErrorNotReady) return r;
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((r = query()) == hipErrorNotReady) {
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_timeout_seconds()) {
+            g_last_error = "timed out waiting for the engine's stream (UKFB_WAIT_TIMEOUT_S)";
+            return hipErrorNotReady;
+        }
     }
     return r;
 }
-static hipError_t wait_event_polling(hipEvent_t ev) {
-    hipError_t r;
-    while ((r = hipEventQuery(ev)) == hipErrorNotReady) {
-    }
-    return r;
-}
+static hipError_t wait_stream_polling(hipStream_t s) { return wait_polling([s] { return hipStreamQuery(s); }); }
+static hipError_t wait_event_polling(hipEvent_t ev) { return wait_polling([ev] { return hipEventQuery(ev); }); }
 
 extern "C" {
 
@@ -325,28 +355,7 @@ int ukfb_default_config(ukfb_config* cfg) {
     return UKFB_OK;
 }
 
-int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream) {
-    if (!out || capacity <= 0 || (model != UKFB_MODEL_POSE && model != UKFB_MODEL_ORIENT) ||
-        (precision != UKFB_F64 && precision != UKFB_F32))
-        return fail(UKFB_ERR_INVALID_ARG, "ukfb_create: bad argument");
-    int ndev = 0;
-    hipError_t err = hipGetDeviceCount(&ndev);
-    if (err != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
-        g_last_error = "ukfb_create: no usable HIP device (the engine has no CPU fallback)";
-        return UKFB_ERR_NO_DEVICE;
-    }
-    HIP_TRY(hipSetDevice(device));
-    ukfb_engine* e = new (std::nothrow) ukfb_engine();
-    if (!e) return fail(UKFB_ERR_INVALID_ARG, "out of host memory");
-    e->model = model;
-    e->prec = precision;
-    e->cap = capacity;
-    e->device = device;
-    e->S = model == UKFB_MODEL_POSE ? 13 : 14;
-    e->D = model == UKFB_MODEL_POSE ? 12 : 13;
-    e->PK = e->D * (e->D + 1) / 2;
-    e->tsize = precision == UKFB_F64 ? 8 : 4;
-    ukfb_default_config(&e->cfg);
+static int create_engine(ukfb_engine* e, int64_t capacity, void* stream) {
     if (stream) {
         e->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -380,7 +389,7 @@ int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, i
     HIP_TRY(hipMemsetAsync(e->Q_stage, 0, n * 9 * ts, e->stream));
     e->Rn_host.assign(size_t(e->D) * e->D, 0.0);
     int rc;
-    if (model == UKFB_MODEL_POSE)  // acceleration.mu = NaN until set (PoseUKF.cpp:109)
+    if (e->model == UKFB_MODEL_POSE)  // acceleration.mu = NaN until set (PoseUKF.cpp:109)
         rc = fill_scalar(e, e->in_a, n * 3, std::numeric_limits<double>::quiet_NaN());
     else
         rc = fill_scalar(e, e->in_a, n * 3, 0.0);
@@ -388,8 +397,39 @@ int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, i
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    rc = rebuild_racc(e);
-    if (rc) return rc;
+    return rebuild_racc(e);
+}
+
+int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream) {
+    if (!out || capacity <= 0 || (model != UKFB_MODEL_POSE && model != UKFB_MODEL_ORIENT) ||
+        (precision != UKFB_F64 && precision != UKFB_F32))
+        return fail(UKFB_ERR_INVALID_ARG, "ukfb_create: bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_last_error = "ukfb_create: no usable HIP device (the engine has no CPU fallback)";
+        return UKFB_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    ukfb_engine* e = new (std::nothrow) ukfb_engine();
+    if (!e) return fail(UKFB_ERR_INVALID_ARG, "out of host memory");
+    e->model = model;
+    e->prec = precision;
+    e->cap = capacity;
+    e->device = device;
+    e->S = model == UKFB_MODEL_POSE ? 13 : 14;
+    e->D = model == UKFB_MODEL_POSE ? 12 : 13;
+    e->PK = e->D * (e->D + 1) / 2;
+    e->tsize = precision == UKFB_F64 ? 8 : 4;
+    ukfb_default_config(&e->cfg);
+    const int rc = create_engine(e, capacity, stream);
+    if (rc) {   // release the stream, the events and every buffer allocated so far; keep the error text
+        const std::string msg = g_last_error;
+        ukfb_destroy(e);
+        g_last_error = msg;
+        return rc;
+    }
     *out = e;
     return UKFB_OK;
 }
@@ -397,14 +437,14 @@ int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, i
 int ukfb_destroy(ukfb_engine* e) {
     if (!e) return UKFB_OK;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
-    void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->in_a, e->in_b, e->z_stage, e->Q_stage,
-                    e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->ev_acc};
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->acc_cov_dev, e->in_a, e->in_b, e->z_stage,
+                    e->Q_stage, e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->ev_acc};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return UKFB_OK;
 }
@@ -503,6 +543,7 @@ int ukfb_get_status_summary(ukfb_engine* e, uint32_t* or_of_all) {
     HIP_TRY(hipMemsetAsync(e->reduce_word, 0, sizeof(uint32_t), e->stream));
     const int blocks = int(std::min<int64_t>((e->cap + 255) / 256, 1024));
     hipLaunchKernelGGL(or_reduce_kernel, dim3(blocks), dim3(256), 0, e->stream, e->status, e->cap, e->reduce_word);
+    HIP_TRY(hipGetLastError());
     return download_raw(e, e->reduce_word, or_of_all, 1);
 }
 

@@ -300,6 +300,7 @@ template <class T> UKFB_DEV void so3_boxminus(const T (&q)[4], const T (&other)[
 template <class T> struct ProcIn {
     T dt;
     T a[3];       // Pose: acc.mu ; Orient: acceleration.mu
+    T adt[3];     // Pose (tuned kernel): use_acc ? acc.mu * dt : 0, the velocity increment of every sigma point
     T w[3];       // Orient: rotation_rate.mu
     bool use_acc; // Pose: acc.mu.allFinite()   (PoseUKF.cpp:188)
     T ninv_tau_g, ninv_tau_a;  // Orient: -1/tau

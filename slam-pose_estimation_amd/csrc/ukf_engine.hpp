@@ -29,6 +29,8 @@ struct ukfb_engine {
     // process noise: batch-uniform D*D, or per filter after ukfb_set_process_noise_per_filter
     void* Rn = nullptr;
     void* Racc = nullptr;  // Pose: acceleration-branch noise (Rn with the velocity block replaced)
+    int64_t Racc_mats = 0; // matrices Racc has room for (1, or capacity once the noise is per filter)
+    void* acc_cov_dev = nullptr;  // 9 doubles' worth of staging for rebuild_racc (persistent)
     bool Rn_per_filter = false;
     std::vector<double> Rn_host;  // uniform copy
 

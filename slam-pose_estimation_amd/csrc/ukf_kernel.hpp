@@ -266,8 +266,10 @@ UKFB_DEV T process_noise_entry(const T* Rn, const T* ROT, const KArgs<T>& a, con
     return scale * val;
 }
 
-// minimum waves per SIMD the register allocator must leave room for (LDS admits about this many)
-template <class T> constexpr int min_waves_per_simd() { return 2; }
+// minimum waves per SIMD the register allocator must leave room for.  fp64: 1, i.e. the whole 512-register file --
+// at 2 the OrientationState instantiations of this (ablation) layout needed 12..64 bytes of scratch, and spilled code
+// is not trusted with this toolchain (note in ukf_kernel16.hpp); tools/check_resources.py rejects scratch in ANY kernel.
+template <class T> constexpr int min_waves_per_simd() { return sizeof(T) == 8 ? 1 : 2; }
 
 template <class T, class M, int G, bool DO_PREDICT, bool DO_UPDATE>
 __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const KArgs<T> a) {

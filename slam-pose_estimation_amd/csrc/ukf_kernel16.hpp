@@ -267,12 +267,15 @@ template <class T, int D, int LS, int KS = D> UKFB_DEV T chol16(T (&a)[D], T* Lc
     return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l)
 }
 
-// row l of a packed lower-triangular matrix; entries beyond the diagonal are never consumed
-// (chol16 only publishes and updates entries j <= l), so they are left as whatever was read
+// Row l of a packed lower-triangular matrix for chol16: one base address and immediate offsets, no selects.  The
+// entries beyond the diagonal are whatever follows the row in the packed array (finite; chol16 updates them along
+// with the rest -- they cannot be kept at zero, steps k <= l touch them -- and masks them when it publishes a column).
 template <class T, int D> UKFB_DEV void load_row(const T* PKS, int l, T (&row)[D]) {
     const int lr = (l < D) ? l : (D - 1);
+    const T* p = PKS + lr * (lr + 1) / 2;
+    // the last row is complete, a shorter row l reads at most index l (l + 1) / 2 + D - 1 < D (D + 1) / 2
 #pragma unroll
-    for (int j = 0; j < D; ++j) row[j] = PKS[lr * (lr + 1) / 2 + ((j <= lr) ? j : 0)];
+    for (int j = 0; j < D; ++j) row[j] = p[j];
 }
 
 // scaled column l of the factor (the stored column already has zeros above the diagonal);
@@ -302,9 +305,9 @@ template <class T> UKFB_DEV void rot_minus_n(const T (&qx)[4], const T (&qy)[4],
 
 // process models with the fast exp (same statements as PoseM/OrientM::process)
 template <class T> UKFB_DEV void process_fast(PoseM<T>*, T (&x)[13], const ProcIn<T>& in) {
-    x[7] += in.use_acc ? in.dt * in.a[0] : T(0);
-    x[8] += in.use_acc ? in.dt * in.a[1] : T(0);
-    x[9] += in.use_acc ? in.dt * in.a[2] : T(0);
+    x[7] += in.adt[0];
+    x[8] += in.adt[1];
+    x[9] += in.adt[2];
     T q[4] = {x[3], x[4], x[5], x[6]};
     const T v[3] = {x[7], x[8], x[9]}, w[3] = {x[10], x[11], x[12]};
     T rv[3], rw[3], e[4], r[4];
@@ -488,8 +491,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         const bool use_ts = a.ts != nullptr;
         noev = use_ts && (ts_l < 0);
         const bool first = use_ts && (last_l == 0) && !noev;
-        const double dt_ts = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
-        const double dt = use_ts ? dt_ts : (a.dt ? dt_l : a.dt_uniform);
+        double dt = a.dt ? dt_l : a.dt_uniform;
+        if (use_ts)   // scalar branch (kernel argument): the IEEE division of base::Time::toSeconds only where it is needed
+            dt = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
         ts_store = use_ts && live && l == 0 && !noev && (first || dt > a.min_dt);
         const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
         const uint32_t code = first ? ST_SKIPPED_FIRST_TS
@@ -508,6 +512,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             pin.w[k] = a.in_b ? pin.w[k] : T(0);
         }
         pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pin.adt[k] = pin.use_acc ? pin.dt * pin.a[k] : T(0);
     }
     bool do_u = false;
     int mid = -1;
@@ -581,7 +587,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             // (tangent >= NL) of the sigma points are centre +- scale * L[c][l] exactly, so their mean IS the centre
             // (ukfom's iteration finds a correction at rounding level) and their deltas are the signed factor rows.
 #pragma unroll
-            for (int s = 0; s < S; ++s) ref[s] = row_bcast<D>(xp[s]);
+            for (int s = 0; s < S; ++s)
+                if (s < NL + 1) ref[s] = row_bcast<D>(xp[s]);   // stored 0..NL: the nonlinear components incl. the quaternion
             const bool has_p = has_pair || has_ctr, has_m = has_pair;
             const T wp = has_p ? T(1) : T(0), wm = has_m ? T(1) : T(0);
 
@@ -665,11 +672,15 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         roww[t] = T(0.5) * (xp[st_of(t)] - xm[st_of(t)]);
                     }
             }
-            {   // mean staging: everything but the quaternion now, the quaternion after the loop (lane 0)
+            {   // mean staging: the nonlinear Euclidean part from lane 0 (the quaternion follows after the loop), the
+                // affine part straight from the centre lane, which holds it
                 T* dst = (pc && l == 0) ? MUS : DUMP;
+                T* dstc = (pc && has_ctr) ? MUS : DUMP;
 #pragma unroll
-                for (int s = 0; s < S; ++s)
-                    if (s < Q || s >= Q + 4) dst[s] = ref[s];
+                for (int s = 0; s < S; ++s) {
+                    if (s >= NL + 1) dstc[s] = xp[s];
+                    else if (s < Q || s >= Q + 4) dst[s] = ref[s];
+                }
             }
             sfence();
             UKFB_MARK("p_mean_it");
@@ -740,6 +751,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
             // (it would hold 2 x TR x TC products in flight across the loop)
             constexpr bool NZ_EARLY = (M::MODEL == 0);
+            constexpr bool TILES_INSIDE = (M::MODEL == 0);   // Pose: every tile entry is a valid (row, column); Orient: rows 13, 14 are not
+            static_assert(!TILES_INSIDE || (10 + TR <= D && 3 + TC <= NL), "Pose tile table");
             constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
             const T* Rn = a.Rn + fc * a.Rn_stride;
             const T* Ra = a.Racc + fc * a.Rn_stride;
@@ -772,7 +785,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
                         for (int j2 = 0; j2 < TC; ++j2) {
                             const int r = R0 + i2, c = C0 + j2;
-                            const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
                             nz[i2][j2] = Ra[rc * D + cc];
                         }
 #pragma unroll
@@ -783,7 +796,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
                         for (int j2 = 0; j2 < TC; ++j2) {
                             const int r = R0 + i2, c = C0 + j2;
-                            const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
                             nz[i2][j2] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
                         }
 #pragma unroll
@@ -815,8 +828,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
                     for (int j2 = 0; j2 < TC; ++j2) {
                         const int r = R0 + i2, c = C0 + j2;
-                        const bool w = writer && r < D && c <= r;
-                        const int rc = (r < D) ? r : (D - 1), cc = (c < D) ? c : (D - 1);
+                        const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
+                        const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
                         const T nv = NZ_EARLY ? nz[i2][j2] : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
                         const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
                         PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;

@@ -3,6 +3,11 @@
 // with the CPU oracle.  Inputs are fixed constants so both sides can restate them.
 #include <pose_estimation/orientation_estimator/OrientationUKF.hpp>
 #include <pose_estimation/pose_with_velocity/PoseUKF.hpp>
+#include <pose_estimation/Batch.hpp>
+#include <pose_estimation/GravitationalModel.hpp>
+
+#include <cmath>
+#include <limits>
 
 #include <cstdio>
 
@@ -88,7 +93,30 @@ int main()
     OrientationUKF::RotationRate::Mu rr = g.getRotationRate();
     std::printf("\"threw_nonfinite\": %s, \"rotation_rate\": [%.17g, %.17g, %.17g], \"wgs84\": %.17g,\n", threw_nonfinite ? "true" : "false", rr[0], rr[1], rr[2],
                 GravitationalModel::WGS_84(0.92698121, 10.0));
-    print_state("orient", mo, 14, Po.data(), 13, true);
+    print_state("orient", mo, 14, Po.data(), 13, false);
+
+    // ---------------- BatchOrientationUKF: a prediction BEFORE any IMU sample must use the constructor's latches
+    // (rotation_rate = 0, acceleration = (0, 0, gravity), OrientationUKF.cpp:49-50) exactly as the scalar class does
+    double mu0[14]; o0.toArray(mu0);
+    OrientationUKF scalar(o0, Q0, 3600.0, 1800.0, loc);
+    scalar.setProcessNoiseCovariance(Rn);
+    scalar.predictionStep(0.02);
+    OrientationState os; OrientationUKF::Covariance Ps; scalar.getCurrentState(os, Ps);
+    double ms[14]; os.toArray(ms);
+    const double earth[3] = {EARTHW * std::cos(loc.latitude), 0.0, EARTHW * std::sin(loc.latitude)};
+    BatchOrientationUKF batch(3, 3600.0, 1800.0, earth);
+    batch.setProcessNoiseCovariance(Rn.data());
+    double mu3[3 * 14], cov3[3 * 169];
+    for (int i = 0; i < 3; ++i) { for (int k = 0; k < 14; ++k) mu3[i * 14 + k] = mu0[k]; for (int k = 0; k < 169; ++k) cov3[i * 169 + k] = Q0.data()[k]; }
+    batch.initializeFilters(0, 3, mu3, cov3);
+    batch.predictionStep(0.02);
+    batch.getCurrentStates(0, 3, mu3, cov3);
+    double dmax = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 14; ++k) dmax = std::fmax(dmax, std::fabs(mu3[i * 14 + k] - ms[k]));
+        for (int k = 0; k < 169; ++k) dmax = std::fmax(dmax, std::fabs(cov3[i * 169 + k] - Ps.data()[k]));
+    }
+    std::printf("\"batch_orient_vs_scalar\": %.3g, \"batch_orient_dvz\": %.3g\n", dmax, mu3[6] - mu0[6]);
     std::printf("}\n");
     return 0;
 }

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Build gate for the tuned kernels (ukf_kernel16): no scratch, no AGPR.
+"""Build gate for EVERY shipped kernel instantiation (ukf_kernel16 and the generic ukf_kernel): no scratch; tuned kernels also no AGPR.
 
 ROCm 7.2's hipcc places VGPR spill / live-range-split copies at the join label of a divergent `if`
 in front of the EXEC restore; reached through s_cbranch_execz they save nothing (see the note in
-slam-pose_estimation_amd/csrc/ukf_kernel16.hpp).  A tuned kernel that needs spills is therefore
+slam-pose_estimation_amd/csrc/ukf_kernel16.hpp).  A kernel that needs spills is therefore
 rejected at build time instead of being trusted.  Usage: check_resources.py <hipcc remark log>..."""
 import re
 import sys
@@ -34,13 +34,13 @@ def main(paths):
             if "ukf_kernel" not in k["name"]:
                 continue
             rows.append(k)
-            if "ukf_kernel16" in k["name"] and (k.get("scratch", 0) or k.get("agpr", 0)):
+            if k.get("scratch", 0) or ("ukf_kernel16" in k["name"] and k.get("agpr", 0)):
                 bad.append(k)
     for k in rows:
         print(f"{k['name'][:70]:70s} vgpr={k.get('vgpr')} agpr={k.get('agpr')} scratch={k.get('scratch')} "
               f"occ={k.get('occupancy')}")
     if bad:
-        print("ERROR: tuned kernels with spills (unsafe with this toolchain):", [b["name"] for b in bad])
+        print("ERROR: kernels with spills (unsafe with this toolchain):", [b["name"] for b in bad])
         return 1
     return 0
 

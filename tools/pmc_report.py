@@ -69,15 +69,18 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5"):
     clock_mhz = grbm / 8.0 / (ns * 1e-9) / 1e6
     e = {"config": name, "kernel": kern, "filters_per_launch": n, "precision": prec,
          "valu_insts_per_wave": valu / waves, "lds_insts_per_wave": lds / waves,
-         "issue_cycles_per_valu_inst": 4.0 * act / valu,          # SQ_ACTIVE_INST_VALU counts quad-cycles
+         # issue cost of one wave64 VALU instruction on a SIMD (MI355X_MICROARCH.md, cycle constants): fp64 moves 16 lanes
+         # per cycle = 4 cycles; fp32 sustains one instruction per 2 cycles when several waves interleave
+         "issue_cycles_per_valu_inst": 4.0 if prec == "f64" else 2.0,
+         "sq_active_quadcycles_per_inst": act / valu,             # per-wave activity (overlaps between waves of a SIMD)
          "valu_active_cycles_per_wave": 4.0 * act / waves, "wave_cycles_per_wave": 4.0 * wcyc / waves,
          "clock_mhz": clock_mhz, "kernel_ms_in_pass": ns * 1e-6,
-         "valu_busy_frac_in_pass": (4.0 * act) / (1024 * clock_mhz * 1e6 * ns * 1e-9),
+         "valu_issue_frac_in_pass": (valu * (4.0 if prec == "f64" else 2.0)) / (1024 * clock_mhz * 1e6 * ns * 1e-9),
          "source": f"rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... GRBM_GUI_ACTIVE, tools/pmc_configs.sh ({tag})"}
     pmc.append(e)
     lines.append(f"{name:13s} {kern:34s} n={n:8d} traffic {hbm / 1e9:7.3f} GB/launch (alg {bench['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f}) "
-                 f"VALU/wave {e['valu_insts_per_wave']:.0f} LDS/wave {e['lds_insts_per_wave']:.0f} cyc/inst {e['issue_cycles_per_valu_inst']:.2f} "
-                 f"clock {clock_mhz:.0f} MHz kernel {ns * 1e-6:.3f} ms VALU busy {e['valu_busy_frac_in_pass']:.3f}")
+                 f"VALU/wave {e['valu_insts_per_wave']:.0f} LDS/wave {e['lds_insts_per_wave']:.0f} cyc/inst {e['issue_cycles_per_valu_inst']:.0f} "
+                 f"clock {clock_mhz:.0f} MHz kernel {ns * 1e-6:.3f} ms VALU issue frac {e['valu_issue_frac_in_pass']:.3f}")
 json.dump({"note": "HBM bytes per launch of the fused kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), corrected with "
                    "factors calibrated on the engine's own access pattern (tools/calib_traffic.hip, tools/pmc_configs.sh)",
            "entries": traffic}, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)

@@ -42,6 +42,12 @@ UKFB_DEV bool m_finite(float x) { return isfinite(x); }
 
 enum { QX = 0, QY = 1, QZ = 2, QW = 3 };
 
+// Wave-uniform votes straight from the compare mask (v_cmp into an SGPR pair + scalar test).  HIP's __any / __all go
+// through an integer (v_cndmask 0/1, v_cmp_ne, s_cmp): two vector instructions more per vote, and the hot path votes
+// about thirty times (every exp / log asks whether any lane needs its wide-angle path).
+UKFB_DEV bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+UKFB_DEV bool wave_all(bool b) { return __builtin_amdgcn_ballot_w64(b) == __builtin_amdgcn_ballot_w64(true); }
+
 // ---------------------------------------------------------------------------------------------
 // Fast, division-free primitives for the tuned kernel (ukf_kernel16.hpp).  All are accurate to a
 // few ulp of T, far inside the 1e-9 (f64) / 1e-4 (f32) parity budget, and replace the ocml
@@ -116,13 +122,13 @@ UKFB_DEV float m_abs(float x) { return __builtin_fabsf(x); }
 // their inlined large-argument paths cost ~100 live registers per call site.
 template <class T> UKFB_DEV void cos_sinc_fast(T y, T& c, T& s) {
     const bool small = y <= Poly<T>::Y_SMALL;
-    const bool any_large = __any(!small);   // wave-uniform: the doubling steps below are skipped on the common path
+    const bool any_large = wave_any(!small);   // wave-uniform: the doubling steps below are skipped on the common path
     const bool big = !(y <= T(4) * Poly<T>::Y_SMALL);
     T yy = y;
     T ratio = T(1);
     if (any_large) {
         yy = small ? y : T(0.25) * y;
-        if (__any(big)) {
+        if (wave_any(big)) {
             const T rs = fast_rsqrt(big ? y : T(1));         // 1/x
             const T x = y * rs;
             const T k = m_rint(x * TwoPi<T>::inv);
@@ -164,7 +170,7 @@ template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
     const T u = v2 * rw * rw;
     T s = T(2) * rw * poly_atan_ratio(u);
     const bool big = !(u <= Poly<T>::U_SMALL);
-    if (__any(big)) {
+    if (wave_any(big)) {
         const T n2 = fma(w, w, v2);
         const T n = n2 * fast_rsqrt(n2);
         const T r1 = fast_rcp(m_abs(w) + n);
@@ -195,7 +201,7 @@ template <class T> UKFB_DEV void so3_log_fast_n(const T (&q)[4], T nrm, T (&r)[3
     const T t1 = v2 * r1 * r1;                           // tan^2(phi/2)
     T s = T(4) * r1 * poly_atan_ratio(t1);
     const bool big = !(t1 <= Poly<T>::U_SMALL);          // also w + |q| <= 0 (angle >= pi) and NaN
-    if (__any(big)) {
+    if (wave_any(big)) {
         const T r1b = fast_rcp(m_abs(w) + nrm);
         const T t1b = v2 * r1b * r1b;                    // tan^2(phi/2) <= 1 with phi = atan(|vec| / |w|)
         const T q2 = T(1) + t1b;

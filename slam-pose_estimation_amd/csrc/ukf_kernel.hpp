@@ -187,7 +187,7 @@ UKFB_DEV bool mean_loop_state(const T (&X)[RND][M::S], T (&ref)[M::S], T* DX, T*
         it += (active && more) ? 1 : 0;
         conv = conv && !(active && capped);
         active = active && more && !capped;
-        if (!__any(active)) break;
+        if (!wave_any(active)) break;
     }
     return conv;
 }
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 
     // =========================================================================== predict
     if constexpr (DO_PREDICT) {
-        if (__any(do_p)) {
+        if (wave_any(do_p)) {
             ProcIn<T> pin;
             pin.dt = dtT;
             pin.ninv_tau_g = a.ninv_tau_g;
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
     for (int t = 0; t < EPL; ++t) Pu[t] = T(0);
 
     if constexpr (DO_UPDATE) {
-        if (__any(do_u)) {
+        if (wave_any(do_u)) {
             {
                 const int zi = (l < 3) ? l : 0, qi = (l >= 3 && l < 12) ? (l - 3) : 0;
                 const T zv = a.z[fc * 3 + zi], qv = a.Q[fc * 9 + qi];
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 #pragma unroll
             for (int k = 0; k < 4; ++k) zref[k] = gshfl<G>(Z[0][k], 0);
             bool zconv = true;
-            const bool any_so3 = __any(so3);
+            const bool any_so3 = wave_any(so3);
             {
                 bool active = true;
                 int it = 0;
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
                     it += (active && more) ? 1 : 0;
                     zconv = zconv && !(active && capped);
                     active = active && more && !capped;
-                    if (!__any(active)) break;
+                    if (!wave_any(active)) break;
                 }
             }
             // ---- final deltas: dz_i = Z_i - zbar, dx_i = X_i - mu
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
 
     // =========================================================================== commit
     const bool changed = p_commit || u_commit;
-    if (__any(changed)) {
+    if (wave_any(changed)) {
 #pragma unroll
         for (int t = 0; t < EPL; ++t) PKS[(ev[t] && u_commit) ? (l + G * t) : (LY::DUM_OFF - LY::PKS_OFF)] = Pu[t];
         {

@@ -72,20 +72,37 @@ template <int B, int E, class F> UKFB_DEV void static_for(F&& f) {
     }
 }
 // xor-1, xor-2 inside quads, then mirrored halves: every lane of the row ends with the same bits.
-template <class T> UKFB_DEV T row_allreduce(T v) {
+UKFB_DEV float row_allreduce(float v) {
     v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);   // row_half_mirror
     v += dpp_mov<0x140>(v);   // row_mirror
     return v;
 }
+// fp64: a butterfly step costs three instructions (two 32-bit DPP moves and the add), but row_newbcast works on
+// 64-bit operands, fused into the FMA.  Two butterfly steps leave the quad sums in every lane of a quad; the QUADS
+// quad leaders are then added by broadcast: 6 + QUADS instructions instead of 12, the same bits on every lane.
+// QUADS = 3 when lanes 12..15 are known to contribute nothing.
+template <int QUADS = 4> UKFB_DEV double row_allreduce(double v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    dpp_hazard_fence(v);
+    double t = row_bcast<0>(v);
+    fmac_bcast<4>(t, v, 1.0);
+    fmac_bcast<8>(t, v, 1.0);
+    if constexpr (QUADS > 3) fmac_bcast<12>(t, v, 1.0);
+    return t;
+}
 
 // K row sums at once (DPP butterflies).  An LDS transposition (lane c adds up component c) was measured for
 // fp64, where a butterfly costs 12 VALU: it pays for the 12-wide mean of the prediction only; for K <= 6 the
 // two extra LDS round trips cost more than the saved instructions (Orient fp64 -2.5 %).
-template <class T, int K> UKFB_DEV void row_allreduce_n(T (&v)[K]) {
+template <class T, int K, int QUADS = 4> UKFB_DEV void row_allreduce_n(T (&v)[K]) {
 #pragma unroll
-    for (int c = 0; c < K; ++c) v[c] = row_allreduce(v[c]);
+    for (int c = 0; c < K; ++c) {
+        if constexpr (sizeof(T) == 8) v[c] = row_allreduce<QUADS>(v[c]);
+        else v[c] = row_allreduce(v[c]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -388,6 +405,28 @@ UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const
     return (M::MODEL == 0 && pin.use_acc) ? vacc : vcv;
 }
 
+// (row, column) of packed lower-triangle entries first .. first + 15, one nibble per entry (entries >= 28 read as 0)
+constexpr unsigned long long tri_rows(int first) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int e = first + i;
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        t |= (unsigned long long)((e < 28 ? r : 0) & 15) << (4 * i);
+    }
+    return t;
+}
+constexpr unsigned long long tri_cols(int first) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int e = first + i;
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        t |= (unsigned long long)((e < 28 ? e - r * (r + 1) / 2 : 0) & 15) << (4 * i);
+    }
+    return t;
+}
+
 // minimum waves per SIMD for the register allocator (LDS admits 3 in fp64, 6 in fp32)
 #ifndef UKFB_W64
 #define UKFB_W64 2
@@ -532,7 +571,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 
     // =========================================================================== predict
     if constexpr (DO_PREDICT) {
-        if (__any(do_p)) {
+        if (wave_any(do_p)) {
             UKFB_MARK("p_chol");
             constexpr int NL = LY::NL, ST = LY::ST, TRIP = LY::TRIP;
             // stored index of a nonlinear Euclidean tangent component t (t outside [RT, RT + 3))
@@ -547,7 +586,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
                 // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose
                 // acceleration branch does not rotate its noise (wave-uniform skip)
-                if (M::MODEL != 0 || !__all(pin.use_acc)) {
+                if (M::MODEL != 0 || !wave_all(pin.use_acc)) {
                     T q[4], rot[9];
                     M::orientation(mu_r, q);
                     quat_to_matrix(q, rot);
@@ -693,7 +732,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 bool active = n2 > a.mean_tol * a.mean_tol;
                 int it = 0;
                 if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
-                while (__any(active)) {
+                while (wave_any(active)) {
                     T rp[3], rm[3], mr[3];
                     rot_minus_n(qp, qr, qn2, rp);
                     rot_minus_n(qm, qr, qn2, rm);
@@ -756,20 +795,16 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
             const T* Rn = a.Rn + fc * a.Rn_stride;
             const T* Ra = a.Racc + fc * a.Rn_stride;
-            const bool all_acc = NZ_EARLY && __all(pin.use_acc);
-            // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle
+            const bool all_acc = NZ_EARLY && wave_all(pin.use_acc);
+            // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
+            // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
             int ar[AEL], ac[AEL];
             bool av[AEL];
 #pragma unroll
             for (int t = 0; t < AEL; ++t) {
-                const int e = l + G * t;
-                av[t] = e < NAB;
-                int rr_ = 0;
-#pragma unroll
-                for (int r = 1; r < D - NL; ++r) rr_ += (e >= r * (r + 1) / 2) ? 1 : 0;
-                rr_ = av[t] ? rr_ : 0;
-                ar[t] = NL + rr_;
-                ac[t] = NL + (av[t] ? (e - rr_ * (rr_ + 1) / 2) : 0);
+                av[t] = l + G * t < NAB;
+                ar[t] = NL + int((tri_rows(G * t) >> (4 * l)) & 15ull);
+                ac[t] = NL + int((tri_cols(G * t) >> (4 * l)) & 15ull);
             }
             T acc[TR][TC], nz[TR][TC], anz[AEL];
             {
@@ -854,7 +889,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 
     // =========================================================================== update
     if constexpr (DO_UPDATE) {
-        if (__any(do_u)) {
+        if (wave_any(do_u)) {
             UKFB_MARK("u_stats");
             T zin[3];
 #pragma unroll
@@ -933,11 +968,11 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     }
                 }
             }
-            if (__any(need_q)) {
+            if (wave_any(need_q)) {
                 // Orientation-dependent models (PoseUKF.cpp:28-33, OrientationUKF.cpp:34-39): full sigma-point
                 // path of ukfom::update.  Wave-uniform branch; results are selected per filter below.
                 T zval[4] = {(0 < m) ? zin[0] : T(0), (1 < m) ? zin[1] : T(0), (2 < m) ? zin[2] : T(0), T(0)};
-                if (__any(so3)) {
+                if (wave_any(so3)) {
                     T qe[4];
                     so3_exp_fast(zin, T(1), qe);  // RotationType(SO3::exp(mu)), PoseUKF.cpp:135
 #pragma unroll
@@ -972,10 +1007,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 // ---- mean of Z.  Euclidean: one pass is exact.  SO(3): iterate on the manifold.
                 T zref[4] = {z0[0], z0[1], z0[2], z0[3]};
                 bool zc = true;
-                if (__any(so3 && do_u)) {
+                if (wave_any(so3 && do_u)) {
                     bool active = so3;
                     int it = 0;
-                    while (__any(active)) {
+                    while (wave_any(active)) {
                         T rp[3], rm[3], r0v[3], mr[3];
                         rot_minus(zp, zref, rp);
                         rot_minus(zm, zref, rm);
@@ -1017,7 +1052,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 {
                     T a3[3] = {T(0), T(0), T(0)}, b3[3] = {T(0), T(0), T(0)}, c3[3] = {T(0), T(0), T(0)},
                       d3[3] = {T(0), T(0), T(0)};
-                    if (__any(so3)) {
+                    if (wave_any(so3)) {
                         rot_minus(zp, zref, a3);
                         rot_minus(zm, zref, b3);
                         rot_minus(z0, zref, c3);
@@ -1168,7 +1203,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c <= r; ++c) rr[r * (r + 1) / 2 + c] = rsg[r] * rsg[c];
-            row_allreduce_n<T, 6>(rr);
+            row_allreduce_n<T, 6, (2 * NC <= 12) ? 3 : 4>(rr);   // lanes 12..15: r = log(conj(e0) e0), zero up to ~1e-17
 #pragma unroll
             for (int k = 0; k < 6; ++k) rr[k] *= T(0.5);
             // cross terms of row l with the three rotation columns: sum_j L'[l][j] W_j, W_j = (r+_j - r-_j) / 2 on lane j

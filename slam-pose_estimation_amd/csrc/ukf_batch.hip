@@ -272,26 +272,28 @@ __global__ void events_rank_kernel(const uint32_t* start, int64_t n, uint32_t* r
     rank[k] = r;
     atomicMax(&flags[1], r);
 }
-// round r: the r-th sample (in time order) of every filter goes to the dense per-filter staging arrays
-template <class S, class T>
-__global__ void events_scatter_round_kernel(const int64_t* filt, const int64_t* ts, const int32_t* meas, const S* z, const S* Q,
-                                            const uint32_t* order, const uint32_t* rank, uint32_t round, int64_t n,
-                                            int64_t* ts_dense, int32_t* meas_dense, T* z_dense, T* Q_dense) {
-    const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    if (k >= n || rank[k] != round) return;
-    const int64_t i = order[k], f = filt[i];
-    ts_dense[f] = ts[i];
-    meas_dense[f] = meas[i];
-    for (int c = 0; c < 3; ++c) z_dense[f * 3 + c] = T(z[i * 3 + c]);
-    for (int c = 0; c < 9; ++c) Q_dense[f * 9 + c] = T(Q[i * 9 + c]);
+// first position of every round in the (rank, filter)-ordered event list; off[rounds] = n
+__global__ void events_round_offsets_kernel(const uint32_t* rank_sorted, int64_t n, uint32_t* off) {
+    const int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t r = rank_sorted[p];
+    if (p == 0 || rank_sorted[p - 1] != r) off[r] = uint32_t(p);
+    if (p == n - 1) off[r + 1] = uint32_t(n);
 }
-
-// OR the status words of the round into the accumulator; filters without a sample in this round contribute
-// nothing (their word is the INACTIVE marker only)
-__global__ void accumulate_status_kernel(const uint32_t* st, const int64_t* ts_dense, uint32_t* acc, int64_t n) {
-    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    if (i >= n) return;
-    if (ts_dense[i] >= 0) acc[i] |= st[i];
+// events in their final (round-major, filter-minor) order, compact and in the engine's precision: what the
+// indirect launches of the fused kernel read directly (no per-round scatter, no capacity-sized staging)
+template <class S, class T>
+__global__ void events_gather_kernel(const int64_t* filt, const int64_t* ts, const int32_t* meas, const S* z, const S* Q,
+                                     const uint32_t* order, int64_t n, int32_t* fidx_c, int64_t* ts_c, int32_t* meas_c, T* z_c,
+                                     T* Q_c) {
+    const int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    const int64_t i = order[p];
+    fidx_c[p] = int32_t(filt[i]);
+    ts_c[p] = ts[i];
+    meas_c[p] = meas[i];
+    for (int c = 0; c < 3; ++c) z_c[p * 3 + c] = T(z[i * 3 + c]);
+    for (int c = 0; c < 9; ++c) Q_c[p * 9 + c] = T(Q[i * 9 + c]);
 }
 
 __global__ void or_reduce_kernel(const uint32_t* st, int64_t n, uint32_t* out) {
@@ -439,7 +441,7 @@ int ukfb_destroy(ukfb_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->acc_cov_dev, e->in_a, e->in_b, e->z_stage,
-                    e->Q_stage, e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->ev_acc};
+                    e->Q_stage, e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -887,13 +889,14 @@ struct Carver {   // bump allocator over the workspace (256-byte aligned pieces)
 template <class S>
 int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const int64_t* d_t, const int32_t* d_m, const S* d_z,
                           const S* d_q, size_t ws_offset, uint32_t* status_or, int64_t* rounds) {
+    if (e->cap > 0x7fffffff) return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events: capacity exceeds 32-bit filter indices");
     const int bits_f = std::max(1, int(std::ceil(std::log2(double(std::max<int64_t>(e->cap, 2))))));
     size_t tmp_sort_t = 0, tmp_sort_f = 0, tmp_scan = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort_t, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr),
                                                static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, 64,
                                                e->stream));
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort_f, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
-                                               static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, bits_f,
+                                               static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, 32,
                                                e->stream));
     HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
                                               hipcub::Max(), int(n), e->stream));
@@ -903,6 +906,7 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     uint32_t* idx_a = c.take<uint32_t>(ne);
     uint32_t* idx_b = c.take<uint32_t>(ne);
     uint32_t* idx_c = c.take<uint32_t>(ne);
+    uint32_t* idx_d = c.take<uint32_t>(ne);
     int64_t* key_t_a = c.take<int64_t>(ne);
     int64_t* key_t_b = c.take<int64_t>(ne);
     uint32_t* key_f_a = c.take<uint32_t>(ne);
@@ -910,12 +914,20 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     uint32_t* head = c.take<uint32_t>(ne);
     uint32_t* start = c.take<uint32_t>(ne);
     uint32_t* rank = c.take<uint32_t>(ne);
+    uint32_t* rank_sorted = c.take<uint32_t>(ne);
+    uint32_t* off = c.take<uint32_t>(ne + 1);
+    int32_t* fidx_c = c.take<int32_t>(ne);
+    int64_t* ts_c = c.take<int64_t>(ne);
+    int32_t* meas_c = c.take<int32_t>(ne);
+    char* z_c = c.take<char>(3 * ne * e->tsize);
+    char* Q_c = c.take<char>(9 * ne * e->tsize);
     uint32_t* flags = c.take<uint32_t>(2);
     char* tmp = c.take<char>(tmp_bytes);
     if (ws_offset + c.used > e->ev_bytes) return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events: workspace too small (internal)");
-    if (!e->ev_acc) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ev_acc), size_t(e->cap) * sizeof(uint32_t)));
 
-    const int blocks = int((n + 255) / 256), cap_blocks = int((e->cap + 255) / 256);
+    // ---- ordering, all on the device: by timestamp, then (stable) by filter = per-filter time order; the position of
+    // a sample inside its filter's run is its round; then (stable) by round = round-major, filter-minor
+    const int blocks = int((n + 255) / 256);
     HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), e->stream));
     hipLaunchKernelGGL(events_init_kernel, dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, n, e->cap, idx_a, key_t_a, flags);
     size_t tb = tmp_bytes;
@@ -927,30 +939,46 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     tb = tmp_bytes;
     HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, start, hipcub::Max(), int(n), e->stream));
     hipLaunchKernelGGL(events_rank_kernel, dim3(blocks), dim3(256), 0, e->stream, start, n, rank, flags);
+    tb = tmp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, rank, rank_sorted, idx_c, idx_d, int(n), 0, 32, e->stream));
+    hipLaunchKernelGGL(events_round_offsets_kernel, dim3(blocks), dim3(256), 0, e->stream, rank_sorted, n, off);
+    if (e->prec == UKFB_F64)
+        hipLaunchKernelGGL((events_gather_kernel<S, double>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z, d_q, idx_d,
+                           n, fidx_c, ts_c, meas_c, reinterpret_cast<double*>(z_c), reinterpret_cast<double*>(Q_c));
+    else
+        hipLaunchKernelGGL((events_gather_kernel<S, float>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z, d_q, idx_d,
+                           n, fidx_c, ts_c, meas_c, reinterpret_cast<float*>(z_c), reinterpret_cast<float*>(Q_c));
+    HIP_TRY(hipGetLastError());
+    // ---- the one host read of the call: input validity, number of rounds and where each round starts (launch
+    // geometry has to be known on the host)
     uint32_t hflags[2] = {0, 0};
     int rc = download_raw(e, flags, hflags, 2);
     if (rc) return rc;
     if (hflags[0]) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
     const int64_t nrounds = int64_t(hflags[1]) + 1;
+    std::vector<uint32_t> hoff(size_t(nrounds) + 1);
+    rc = download_raw(e, off, hoff.data(), hoff.size());
+    if (rc) return rc;
 
-    HIP_TRY(hipMemsetAsync(e->ev_acc, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
+    // ---- one indirect fused launch per round over exactly the filters that have a sample in it: the cost of the
+    // call follows the number of events, not rounds x capacity.  Status words accumulate (OR) across rounds.
+    HIP_TRY(hipMemsetAsync(e->status, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
     for (int64_t r = 0; r < nrounds; ++r) {
-        HIP_TRY(hipMemsetAsync(e->ts_stage, 0xFF, size_t(e->cap) * sizeof(int64_t), e->stream));     // -1: no sample
-        HIP_TRY(hipMemsetAsync(e->meas_stage, 0xFF, size_t(e->cap) * sizeof(int32_t), e->stream));   // -1: no measurement
-        if (e->prec == UKFB_F64)
-            hipLaunchKernelGGL((events_scatter_round_kernel<S, double>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z,
-                               d_q, idx_c, rank, uint32_t(r), n, e->ts_stage, e->meas_stage, static_cast<double*>(e->z_stage),
-                               static_cast<double*>(e->Q_stage));
-        else
-            hipLaunchKernelGGL((events_scatter_round_kernel<S, float>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z,
-                               d_q, idx_c, rank, uint32_t(r), n, e->ts_stage, e->meas_stage, static_cast<float*>(e->z_stage),
-                               static_cast<float*>(e->Q_stage));
-        rc = ukfb_cycle_timestamps_dev(e, e->ts_stage, e->meas_stage, e->z_stage, e->Q_stage);
+        const size_t o = hoff[size_t(r)], cnt = size_t(hoff[size_t(r) + 1]) - o;
+        if (cnt == 0) continue;
+        ukfb::LaunchReq q;
+        q.do_predict = true;
+        q.do_update = true;
+        q.ts_dev = ts_c + o;
+        q.meas_dev = meas_c + o;
+        q.z_dev = z_c + 3 * o * e->tsize;
+        q.Q_dev = Q_c + 9 * o * e->tsize;
+        q.filter_index_dev = fidx_c + o;
+        q.n_items = int64_t(cnt);
+        q.status_accumulate = true;
+        rc = launch(e, q);
         if (rc) return rc;
-        hipLaunchKernelGGL(accumulate_status_kernel, dim3(cap_blocks), dim3(256), 0, e->stream, e->status, e->ts_stage, e->ev_acc,
-                           e->cap);
     }
-    HIP_TRY(hipMemcpyAsync(e->status, e->ev_acc, size_t(e->cap) * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
     if (rounds) *rounds = nrounds;
     if (status_or) return ukfb_get_status_summary(e, status_or);
     return UKFB_OK;
@@ -960,7 +988,9 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
 // temporary-storage query: 4x the key/value arrays covers rocPRIM's double buffers)
 size_t events_workspace_bytes(int64_t n) {
     const size_t ne = size_t(n);
-    return (3 * 4 + 2 * 8 + 2 * 4 + 3 * 4) * ne + 12 * 256 + (size_t(64) << 20) / 4 + 24 * ne;
+    // 4 index + 2 time-key + 2 filter-key + head/start/rank/rank_sorted/off + compact events (int32, int64, int32,
+    // 12 scalars of <= 8 bytes) + alignment slack + radix-sort temporaries
+    return (4 * 4 + 2 * 8 + 2 * 4 + 5 * 4 + 4 + 8 + 4 + 12 * 8) * ne + 32 * 256 + (size_t(64) << 20) / 4 + 24 * ne;
 }
 
 int ensure_events_arena(ukfb_engine* e, size_t bytes) {

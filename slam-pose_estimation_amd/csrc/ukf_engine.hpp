@@ -50,10 +50,9 @@ struct ukfb_engine {
     double* dt_stage = nullptr;
     int64_t* ts_stage = nullptr;
     uint32_t* reduce_word = nullptr;  // status OR-reduction target
-    // ukfb_process_events: device workspace (grow-only), status accumulator [cap]
+    // ukfb_process_events: device workspace (grow-only)
     void* ev_dev = nullptr;
     size_t ev_bytes = 0;
-    uint32_t* ev_acc = nullptr;
 
     // last launch (for bench.py / profiles)
     std::string last_kernel;
@@ -75,6 +74,10 @@ struct LaunchReq {
     const void* z_dev = nullptr;
     const void* Q_dev = nullptr;
     const uint8_t* active_dev = nullptr;
+    // indirect launch over a list of filters (event rounds): n_items entries of filter_index_dev; -1: every filter
+    const int32_t* filter_index_dev = nullptr;
+    int64_t n_items = -1;
+    bool status_accumulate = false;
 };
 
 int launch_pose_f64(ukfb_engine* e, const LaunchReq& r);

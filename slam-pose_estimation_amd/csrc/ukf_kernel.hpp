@@ -37,8 +37,13 @@ enum : uint32_t {
 };
 
 template <class T> struct KArgs {
-    int64_t n;
-    T* mu;                       // [n][S]
+    int64_t n;                   // work items of this launch (= filters, or entries of fidx)
+    // Indirect launch (event streams): work item i acts on filter fidx[i]; the per-call inputs (ts, dt, meas, active,
+    // z, Q) are indexed by i, the engine's per-filter state (everything else) by the filter.  Null: filter i.
+    // A filter must not appear twice in one launch.
+    const int32_t* fidx;
+    int status_accumulate;       // != 0: OR the new status word into the stored one instead of replacing it
+    T* mu;                       // [filters][S]
     T* cov;                      // [n][PK] packed lower triangle, row-major
     uint32_t* status;            // [n]
     const uint8_t* initialised;  // [n]
@@ -284,7 +289,8 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
     const int g = lane / G, l = lane % G;
     const int64_t f = int64_t(blockIdx.x) * FPW + g;
     const bool fvalid = f < a.n;
-    const int64_t fc = fvalid ? f : (a.n - 1);
+    const int64_t fi = fvalid ? f : (a.n - 1);                    // work item: index of the per-call inputs
+    const int64_t fc = a.fidx ? int64_t(a.fidx[fi]) : fi;         // filter: index of the engine's state
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC_OFF;
     T* DX = base + LY::DX_OFF;
@@ -315,13 +321,13 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
         double dt;
         bool first = false;
         if (a.ts) {
-            const int64_t last = a.last_ts[fc], ts = a.ts[fc];
+            const int64_t last = a.last_ts[fc], ts = a.ts[fi];
             noev = ts < 0;                       // event streams: this filter has no sample in this call
             first = (last == 0) && !noev;
             dt = (first || noev) ? 0.0 : double(ts - last) / 1000000.0;
             if (live && l == 0 && !noev && (first || dt > a.min_dt)) a.last_ts[fc] = ts;
         } else {
-            dt = a.dt ? a.dt[fc] : a.dt_uniform;
+            dt = a.dt ? a.dt[fi] : a.dt_uniform;
         }
         const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
         const uint32_t code = first ? ST_SKIPPED_FIRST_TS
@@ -336,8 +342,8 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
     bool do_u = false;
     int mid = -1;
     if constexpr (DO_UPDATE) {
-        mid = a.meas ? a.meas[fc] : a.meas_uniform;
-        const bool act = M::meas_valid(mid) && (a.active ? a.active[fc] != 0 : true);
+        mid = a.meas ? a.meas[fi] : a.meas_uniform;
+        const bool act = M::meas_valid(mid) && (a.active ? a.active[fi] != 0 : true);
         do_u = live && act && !p_error && !noev;
         st |= (live && !do_u) ? ST_INACTIVE : 0u;
     }
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
         if (wave_any(do_u)) {
             {
                 const int zi = (l < 3) ? l : 0, qi = (l >= 3 && l < 12) ? (l - 3) : 0;
-                const T zv = a.z[fc * 3 + zi], qv = a.Q[fc * 9 + qi];
+                const T zv = a.z[fi * 3 + zi], qv = a.Q[fi * 9 + qi];
                 ZQ[(l < 12) ? l : (LY::DUM_OFF - LY::MISC_OFF - 44)] = (l < 3) ? zv : qv;
             }
             wsync();
@@ -699,11 +705,11 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
         if (changed && fvalid) {
 #pragma unroll
             for (int t = 0; t < EPL; ++t)
-                if (ev[t]) a.cov[f * PK + l + G * t] = PKS[l + G * t];
-            if (l < S) a.mu[f * S + l] = MU[l];
+                if (ev[t]) a.cov[fc * PK + l + G * t] = PKS[l + G * t];
+            if (l < S) a.mu[fc * S + l] = MU[l];
         }
     }
-    if (fvalid && l == 0) a.status[f] = st;
+    if (fvalid && l == 0) a.status[fc] = a.status_accumulate ? (a.status[fc] | st) : st;
 }
 
 }  // namespace ukfb

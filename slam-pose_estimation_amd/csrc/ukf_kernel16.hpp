@@ -449,7 +449,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     const int g = lane >> 4, l = lane & 15;
     const int64_t f = int64_t(blockIdx.x) * FPW + g;
     const bool fvalid = f < a.n;
-    const int64_t fc = fvalid ? f : (a.n - 1);
+    const int64_t fi = fvalid ? f : (a.n - 1);                    // work item: index of the per-call inputs
+    const int64_t fc = a.fidx ? int64_t(a.fidx[fi]) : fi;         // filter: index of the engine's state
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC;
     T* TAB = base + LY::TNL;
@@ -470,8 +471,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     int64_t last_l = 0, ts_l = 0;
     double dt_l = 0.0;
     if constexpr (DO_PREDICT) {
-        const int64_t* tsp = a.ts ? (a.ts + fc) : (a.last_ts + fc);
-        const double* dtp = a.dt ? (a.dt + fc) : reinterpret_cast<const double*>(a.last_ts + fc);
+        const int64_t* tsp = a.ts ? (a.ts + fi) : (a.last_ts + fc);
+        const double* dtp = a.dt ? (a.dt + fi) : reinterpret_cast<const double*>(a.last_ts + fc);
         last_l = a.last_ts[fc];
         ts_l = *tsp;
         dt_l = *dtp;
@@ -479,8 +480,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     int32_t mid_l = 0;
     uint8_t act_b = 1;
     if constexpr (DO_UPDATE) {
-        const int32_t* mp = a.meas ? (a.meas + fc) : reinterpret_cast<const int32_t*>(a.status + fc);
-        const uint8_t* ap = a.active ? (a.active + fc) : (a.initialised + fc);
+        const int32_t* mp = a.meas ? (a.meas + fi) : reinterpret_cast<const int32_t*>(a.status + fc);
+        const uint8_t* ap = a.active ? (a.active + fi) : (a.initialised + fc);
         mid_l = *mp;
         act_b = *ap;
     }
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     }
     T zq_l = T(0);
     if constexpr (DO_UPDATE) {
-        const T* zp = (l < 3) ? (a.z + fc * 3 + l) : (a.Q + fc * 9 + ((l < 12) ? (l - 3) : 0));
+        const T* zp = (l < 3) ? (a.z + fi * 3 + l) : (a.Q + fi * 9 + ((l < 12) ? (l - 3) : 0));
         zq_l = *zp;
     }
 
@@ -1296,11 +1297,11 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const int e = l + G * t;
-            if (e < PK) a.cov[f * PK + e] = PKS[e];
+            if (e < PK) a.cov[fc * PK + e] = PKS[e];
         }
-        if (l < S) a.mu[f * S + l] = MUS[l];
+        if (l < S) a.mu[fc * S + l] = MUS[l];
     }
-    if (fvalid && l == 0) a.status[f] = st;
+    if (fvalid && l == 0) a.status[fc] = a.status_accumulate ? (a.status[fc] | st) : st;
 }
 
 }  // namespace ukfb

@@ -13,7 +13,7 @@ namespace ukfb {
 
 template <class T, class M, int G> static int launch_g(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
     constexpr int FPW = 64 / G;
-    const int64_t grid = (e->cap + FPW - 1) / FPW;
+    const int64_t grid = (args.n + FPW - 1) / FPW;
     const int lds = FPW * lds_bytes_per_filter<T, M>();
     const char* mode = r.do_predict ? (r.do_update ? "cycle" : "predict") : "update";
     e->last_kernel = std::string("ukf_kernel<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
@@ -93,7 +93,7 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
 // tuned kernel: one DPP row per filter (ukf_kernel16.hpp)
 template <class T, class M> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
     constexpr int FPW = 4;
-    const int64_t grid = (e->cap + FPW - 1) / FPW;
+    const int64_t grid = (args.n + FPW - 1) / FPW;
     const int lds = FPW * lds_bytes_per_filter16<T, M>();
     const char* mode = r.do_predict ? (r.do_update ? "cycle" : "predict") : "update";
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
@@ -122,7 +122,9 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
 
 template <class T, class M> static int launch_typed(ukfb_engine* e, const LaunchReq& r) {
     KArgs<T> a{};
-    a.n = e->cap;
+    a.n = r.n_items >= 0 ? r.n_items : e->cap;
+    a.fidx = r.filter_index_dev;
+    a.status_accumulate = r.status_accumulate ? 1 : 0;
     a.mu = static_cast<T*>(e->mu);
     a.cov = static_cast<T*>(e->cov);
     a.status = e->status;

@@ -107,3 +107,16 @@ def test_synthetic_inputs_are_counter_based(spe):
     a1 = spe.synth.pose_cycle_inputs(8, 5, first=100)[0]
     a2 = spe.synth.pose_cycle_inputs(32, 5, first=92)[0][8:16]
     assert np.array_equal(a1, a2)
+
+
+@pytest.mark.parametrize("std", ["c++11", "c++17"])
+def test_caller_text_written_against_the_reference_api_compiles(tmp_path, std):
+    """north_star: 'drops into Rock as-is'.  tests/cpp/reference_caller_text.cpp holds caller statements typed against
+    the reference's Eigen / MTK API (assignable blocks, setZero, MTK::SO3<double>(q), Eigen::Matrix<...> spellings);
+    they must compile -- warnings as errors -- against include/ unchanged and give the reference's results."""
+    import subprocess
+    exe = tmp_path / "caller_text"
+    subprocess.check_call(["g++", f"-std={std}", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "reference_caller_text.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

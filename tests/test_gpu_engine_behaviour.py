@@ -369,3 +369,77 @@ def test_time_ordered_event_stream(spe, oracle, onp):
     # an out-of-range filter index is refused before anything is applied
     with pytest.raises(spe.UkfbError):
         eng.process_events([n], [2_000_000], [0], np.zeros((1, 3)), np.eye(3)[None])
+
+
+def test_event_stream_cost_follows_events_not_rounds_times_capacity(spe, oracle, onp):
+    """A skewed stream: 262 144 filters, one 'chatty' filter with 256 samples, every 64th other filter with one.
+    256 rounds -- but every round is launched over exactly the filters that have a sample in it (indirect filter
+    index), so the call must (a) match the sequential oracle replay, (b) leave every filter without a sample
+    untouched with status 0, (c) take time on the order of the events, far below 256 full-batch launches."""
+    import time
+    import torch
+    n, chatty, k_chatty = 262_144, 7, 256
+    CH = 131_072
+    eng = spe.BatchPoseUKF(n)
+    mus, covs = {}, {}
+    for lo in range(0, n, CH):
+        mu, cov = spe.synth.pose_initial(CH, first=lo)
+        eng.initialize(mu, cov, first=lo)
+        mus[lo], covs[lo] = mu, cov
+    R = spe.synth.pose_default_process_noise()
+    rng = np.random.default_rng(5)
+    singles = np.arange(64, n, 64, dtype=np.int64)
+    f = np.concatenate([np.full(k_chatty, chatty, dtype=np.int64), singles])
+    t = np.concatenate([1_000_000 + 10_000 * np.arange(1, k_chatty + 1, dtype=np.int64),
+                        1_000_000 + rng.integers(1_000, 900_000, singles.size)])
+    m = np.concatenate([np.tile(np.array([0, 4, 8, -1], dtype=np.int32), k_chatty // 4), np.zeros(singles.size, dtype=np.int32)])
+    mu_f = np.concatenate([np.repeat(mus[0][chatty:chatty + 1], k_chatty, axis=0),
+                           np.concatenate([mus[lo] for lo in sorted(mus)])[singles]])
+    z = spe.synth.pose_measurement_for_model(mu_f, np.maximum(m, 0), rng.uniform(-0.02, 0.02, (f.size, 3)))
+    Q = np.tile(np.eye(3) * 0.0025, (f.size, 1, 1))
+    perm = rng.permutation(f.size)
+    f, t, m, z, Q = f[perm], t[perm], m[perm], z[perm], Q[perm]
+    eng.set_last_measurement_time(np.full(n, 1_000_000, dtype=np.int64))
+    d = [torch.from_numpy(f).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(m).cuda(),
+         torch.from_numpy(z).cuda(), torch.from_numpy(Q.reshape(-1, 9)).cuda()]
+    torch.cuda.synchronize()
+    snap = [x.clone() for x in (torch.zeros(1),)]   # noqa: F841  (keeps torch initialised before timing)
+    eng.sync()
+    t0 = time.perf_counter()
+    st_or, rounds = eng.process_events_dev(f.size, *d)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    assert rounds == k_chatty
+    # (c) 256 full-batch launches of this engine take ~90 ms; the event-proportional pipeline a few ms
+    assert elapsed < 0.040, elapsed
+    # (a) sequential replay of the chatty filter and of a sample of the single-sample filters
+    def replay(fi, mu0, cov0):
+        idx = np.where(f == fi)[0]
+        idx = idx[np.argsort(t[idx], kind="stable")]
+        mo, co, last, st = mu0[None].copy(), cov0[None].copy(), np.array([1_000_000], dtype=np.int64), 0
+        for i in idx:
+            nl, dt, gs = oracle.gate_timestamps(np.array([t[i]]), last)
+            last = nl; st |= int(gs[0])
+            if gs[0] == 0:
+                mo, co, s1 = oracle.pose_predict(mo, co, R, None, None, dt)
+                st |= int(s1[0])
+            if m[i] >= 0:
+                mo, co, s2 = oracle.pose_update(mo, co, int(m[i]), z[i][None], Q[i][None])
+                st |= int(s2[0])
+            else:
+                st |= onp.ST_INACTIVE
+        return mo[0], co[0], int(last[0]), st
+    check = [chatty] + [int(x) for x in singles[:: max(1, singles.size // 24)]]
+    for fi in check:
+        lo = (fi // CH) * CH
+        mo, co, last, st = replay(fi, mus[lo][fi - lo], covs[lo][fi - lo])
+        mg, cg, _ = eng.state(fi, 1)
+        assert max_abs(mg[0], mo) <= 1e-9 and max_abs(cg[0], co) <= 1e-9, fi
+        assert int(eng.status(fi, 1)[0]) == st and int(eng.last_measurement_time(fi, 1)[0]) == last
+    # (b) filters without a sample: bit-unchanged, status 0
+    mg, cg, _ = eng.state(0, 64)
+    keep = np.ones(64, dtype=bool); keep[chatty] = False
+    assert max_abs(mg[keep], mus[0][:64][keep]) == 0 and max_abs(cg[keep], covs[0][:64][keep]) == 0
+    st_all = eng.status()
+    touched = np.zeros(n, dtype=bool); touched[f] = True
+    assert (st_all[~touched] == 0).all() and st_or == int(np.bitwise_or.reduce(st_all))

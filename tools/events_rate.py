@@ -40,3 +40,23 @@ for rep in range(3):
     e.sync()
     dt = time.perf_counter() - t0
     print("device-resident: events %d, rounds %d, status_or %d: %.2f ms -> %.1f M events/s" % (E, rounds, st, dt * 1e3, E / dt / 1e6))
+
+# skewed stream: one filter with 256 samples, every 64th filter with one -> 256 rounds; the indirect per-round launches make
+# the cost follow the events (a full-batch launch per round would be 256 x the fused kernel over all n filters)
+k = 256
+singles = np.arange(64, n, 64, dtype=np.int64)
+fs = np.concatenate([np.full(k, 7, dtype=np.int64), singles])
+ts_ = np.concatenate([1_000_000 + 10_000 * np.arange(1, k + 1, dtype=np.int64), 1_000_000 + rng.integers(1_000, 900_000, singles.size)])
+ms = np.zeros(fs.size, dtype=np.int32)
+zs = spe.synth.pose_measurement_for_model(np.concatenate([np.repeat(mu[7:8], k, axis=0), mu[singles]]), ms, rng.uniform(-0.02, 0.02, (fs.size, 3)))
+Qs = np.tile(np.eye(3) * 0.0025, (fs.size, 1, 1))
+ds = [torch.from_numpy(fs).cuda(), torch.from_numpy(ts_).cuda(), torch.from_numpy(ms).cuda(),
+      torch.from_numpy(zs).to("cuda", td), torch.from_numpy(Qs.reshape(-1, 9)).to("cuda", td)]
+for rep in range(3):
+    e.initialize(mu, cov); e.set_last_measurement_time(np.full(n, 1_000_000, dtype=np.int64)); e.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, rounds = e.process_events_dev(fs.size, *ds)
+    e.sync()
+    dt = time.perf_counter() - t0
+    print("skewed, device-resident: events %d, rounds %d, status_or %d: %.2f ms -> %.2f M events/s" % (fs.size, rounds, st, dt * 1e3, fs.size / dt / 1e6))

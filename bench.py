@@ -81,7 +81,7 @@ def parse():
                     help="rehearse launch / rendezvous / sharding / barrier / gather with NO engine and NO timing "
                          "(CPU boxes; prints value null)")
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
-    ap.add_argument("--cpu-sample-seconds", type=float, default=8.0, help="target CPU time of the all-core sample")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=6.0, help="target CPU time of each all-core sample")
     ap.add_argument("--parity-sample", type=int, default=4096)
     return ap.parse_args()
 
@@ -140,6 +140,21 @@ def _threads_available():
         return os.cpu_count() or 1
 
 
+def _cpu_quota():
+    """CPUs' worth of time the container's cgroup may use per period (None: unlimited / unknown)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """Time the oracle (reported baseline only; never the product path): all hardware threads, then one core."""
     import numpy as np
@@ -167,18 +182,32 @@ def cpu_baseline(args):
         return n * cycles / el, cycles, el
 
     with capi.using(native if native is not None else capi.lib()):
-        threads = max(1, min(_threads_available(), capi.max_threads()))
+        hw = max(1, min(_threads_available(), capi.max_threads()))
         n_all = args.cpu_sample_filters
-        v_all, c_all, e_all = run(n_all, threads, args.cpu_sample_seconds)
+        # "All hardware threads" is not automatically the fastest: a container whose CPU share (cgroup quota or
+        # cpuset pressure) is below its visible threads is throttled when every thread spins.  Short probes over a
+        # ladder of thread counts pick the count for the full sample; every probe is reported.
+        quota = _cpu_quota()
+        ladder = sorted({t for t in (hw, hw // 2, hw // 4, 64, 32, 16, 8, int((quota or 0) + 0.999)) if 1 < t <= hw} | {hw})
+        sweep = {}
+        for t in ladder:
+            v, _, _ = run(min(n_all, 8192), t, 0.7)
+            sweep[t] = v
+        t_best = max(sweep, key=sweep.get)
+        v_b, c_b, e_b = run(n_all, t_best, args.cpu_sample_seconds)
+        runs = [(v_b, t_best, c_b, e_b)]
         n_one = max(64, min(n_all, 4096))
         v_one, c_one, e_one = run(n_one, 1, args.cpu_sample_seconds / 2)
-    return {"value": v_all, "unit": "filter-cycles/s", "cores": threads, "kind": "port",
+    best = max(runs, key=lambda r: r[0])
+    return {"value": best[0], "unit": "filter-cycles/s", "cores": best[1], "kind": "port",
+            "hardware_threads": hw, "cgroup_cpu_quota": quota,
+            "thread_sweep": {str(t): v for t, v in sorted(sweep.items())},
             "single_core": {"value": v_one, "cores": 1,
                             "sample": f"{n_one} filters x {c_one} cycles, {e_one:.2f} s"},
             "build": build,
-            "sample": f"{n_all} PoseWithVelocity filters x {c_all} predict(acc)+position-update cycles, "
-                      f"{args.precision}, oracle/ukf_oracle.hpp with OpenMP over filters on {threads} hardware threads, "
-                      f"{e_all:.2f} s"}
+            "sample": f"{n_all} PoseWithVelocity filters x {best[2]} predict(acc)+position-update cycles, "
+                      f"{args.precision}, oracle/ukf_oracle.hpp with OpenMP over filters on {best[1]} threads "
+                      f"({hw} hardware threads visible, cgroup CPU quota {quota}), {best[3]:.2f} s"}
 
 
 def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):

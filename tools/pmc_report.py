@@ -87,7 +87,7 @@ json.dump({"note": "HBM bytes per launch of the fused kernel from rocprofv3 --pm
 json.dump({"note": "per-wave instruction counters and sustained clock of the fused kernel, one SQ/GRBM pass per BASELINE configuration "
                    "(tools/pmc_configs.sh); bench.py turns them into roofline.valu with the kernel time it measures live",
            "entries": pmc}, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
-for t in ("default", "f32"):
+for t in ("default", "f32", "cfg2"):
     for f in glob.glob(os.path.join(out, f"trace_{t}", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(out, f"{tag}_{t}_kernel_stats.csv"))
         for row in csv.DictReader(open(f)):

@@ -494,8 +494,8 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     const T mu_l = a.mu[fc * S + ((l < S) ? l : (S - 1))];
     ProcIn<T> pin;
     if constexpr (DO_PREDICT) {
-        const T* pa = a.in_a ? (a.in_a + fc * 3) : (a.mu + fc * S);
-        const T* pb = a.in_b ? (a.in_b + fc * 3) : (a.mu + fc * S);
+        const T* pa = a.in_a + fc * 3;   // latched inputs: the engine always passes both arrays (its own or the bound ones)
+        const T* pb = a.in_b + fc * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             pin.a[k] = pa[k];
@@ -548,8 +548,6 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             pin.earth[k] = a.earth[k];
-            pin.a[k] = a.in_a ? pin.a[k] : T(NAN);
-            pin.w[k] = a.in_b ? pin.w[k] : T(0);
         }
         pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
 #pragma unroll

@@ -259,14 +259,16 @@ UKFB_DEV void keep(float& x) { asm volatile("" : "+v"(x)); }
 UKFB_DEV void keep(double& x) { asm volatile("" : "+v"(x)); }
 
 // KS < D factorises the first KS columns only (consumers that need no more; pivots KS.. are then not checked).
-template <class T, int D, int LS, int KS = D> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, bool& ok) {
+// PUB <= KS publishes the first PUB columns only (the update's applyDelta reads no others; all KS pivots are still
+// computed and checked).  The columns are published after the last step: column k is final once step k has run, the
+// row stays in registers anyway, and the compiler pairs the stores (ds_write2) when they stand together.
+template <class T, int D, int LS, int KS = D, int PUB = KS> UKFB_DEV T chol16(T (&a)[D], T* Lc, int l, bool& ok) {
+    static_assert(PUB <= KS && KS <= D, "chol16 column counts");
     bool good = true;
     // lanes >= D carry a copy of row D-1 (load_row clamps) and store the same values to the same addresses
     const int lw = (l < D) ? l : (D - 1);
     static_for<0, KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
-        Lc[k * LS + lw] = (l >= k) ? a[k] : T(0);
         const T akk = row_bcast<k>(a[k]);
         good = good && (akk > T(0));
         const T nt = -(a[k] * fast_rcp(akk));   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
@@ -278,10 +280,13 @@ template <class T, int D, int LS, int KS = D> UKFB_DEV T chol16(T (&a)[D], T* Lc
             });
         }
     });
+    // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
+#pragma unroll
+    for (int k = 0; k < PUB; ++k) Lc[k * LS + lw] = (l >= k) ? a[k] : T(0);
     ok = good;
     wsync();
-    const int lc = (l < KS) ? l : (KS - 1);
-    return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l)
+    const int lc = (l < PUB) ? l : (PUB - 1);
+    return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l) (lanes >= PUB: the last published one)
 }
 
 // Row l of a packed lower-triangular matrix for chol16: one base address and immediate offsets, no selects.  The
@@ -531,16 +536,27 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         const bool use_ts = a.ts != nullptr;
         noev = use_ts && (ts_l < 0);
         const bool first = use_ts && (last_l == 0) && !noev;
-        double dt = a.dt ? dt_l : a.dt_uniform;
-        if (use_ts)   // scalar branch (kernel argument): the IEEE division of base::Time::toSeconds only where it is needed
-            dt = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
-        ts_store = use_ts && live && l == 0 && !noev && (first || dt > a.min_dt);
-        const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
-        const uint32_t code = first ? ST_SKIPPED_FIRST_TS
-                                    : (neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u)));
-        st |= (live && !noev) ? code : 0u;
-        p_error = live && !first && !noev && (neg || (!small && large));
-        do_p = live && !noev && code == 0u;
+        double dt;
+        if (!use_ts && !a.dt) {
+            // one dt for the whole launch (kernel argument): the gate is scalar arithmetic, one select per lane
+            dt = a.dt_uniform;
+            const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
+            const uint32_t code = neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u));
+            st |= live ? code : 0u;
+            p_error = live && (neg || (!small && large));
+            do_p = live && code == 0u;
+        } else {
+            dt = a.dt ? dt_l : a.dt_uniform;
+            if (use_ts)   // the IEEE division of base::Time::toSeconds only where it is needed
+                dt = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
+            ts_store = use_ts && live && l == 0 && !noev && (first || dt > a.min_dt);
+            const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
+            const uint32_t code = first ? ST_SKIPPED_FIRST_TS
+                                        : (neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u)));
+            st |= (live && !noev) ? code : 0u;
+            p_error = live && !first && !noev && (neg || (!small && large));
+            do_p = live && !noev && code == 0u;
+        }
         dtT = T(dt);
         pin.dt = dtT;
         pin.ninv_tau_g = a.ninv_tau_g;
@@ -1167,7 +1183,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     srow2[b] = arow2[b];
                     d0[b] = row_bcast<b>(del);
                 });
-                rs2 = chol16<T, D, LS>(arow2, Lc, l, ok2);
+                rs2 = chol16<T, D, LS, D, RT + 3>(arow2, Lc, l, ok2);   // applyDelta reads the first RT + 3 columns only
                 wsync();
             }
             sfence();

@@ -4,7 +4,7 @@
 prec=$1; rounds=$2; shift 2
 for r in $(seq $rounds); do
   for lib in "$@"; do
-    v=$(UKFB_LIB=$PWD/$lib timeout -k 10 200 python bench.py --precision $prec --steps 30 --warmup 5 --no-cpu-baseline $AB_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,1))")
+    v=$(UKFB_LIB=$PWD/$lib timeout -k 10 200 python bench.py --precision $prec --steps ${AB_STEPS:-100} --warmup 10 --no-cpu-baseline --no-parity --no-extra-regions $AB_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,1))")
     echo "$lib $v"
   done
 done | sort | awk '{a[$1]=a[$1]" "$2} END{for(k in a) print k, a[k]}'

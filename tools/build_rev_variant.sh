@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds the engine of another git revision next to the product library, for same-box A/B timing with tools/ab.sh:
+#   tools/build_rev_variant.sh <name> <git-rev>  ->  slam-pose_estimation_amd/lib/ab/<name>.so
+set -e
+name=$1; rev=$2
+root=$(cd "$(dirname "$0")/.." && pwd)
+wt=$(mktemp -d /tmp/ukfb_wt_XXXX)
+git -C $root worktree add -f --detach $wt $rev > /dev/null 2>&1
+src=$wt/slam-pose_estimation_amd/csrc
+out=$root/slam-pose_estimation_amd/lib/ab; obj=$out/obj_$name; mkdir -p $obj
+pids=""
+for tu in ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.log &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o
+rm -rf $obj; git -C $root worktree remove --force $wt
+echo "built $out/$name.so from $rev"

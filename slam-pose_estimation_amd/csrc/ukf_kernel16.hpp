@@ -433,6 +433,11 @@ constexpr unsigned long long tri_cols(int first) {
 }
 
 // minimum waves per SIMD for the register allocator (LDS admits 3 in fp64, 6 in fp32)
+// fp64 first mean iteration: 1 = transpose the NL sums through LDS, 0 = quad sums + broadcast FMAs in registers
+// (same-box A/B: 908 vs 902 M filter-cycles/s for Pose, 582 vs 585 for Orient -- a wash; the transposition stays)
+#ifndef UKFB_MEAN1_TRANSPOSE
+#define UKFB_MEAN1_TRANSPOSE 1
+#endif
 #ifndef UKFB_W64
 #define UKFB_W64 2
 #endif
@@ -665,7 +670,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 for (int t = 0; t < NL; ++t)
                     if (t < RT || t >= RT + 3) loc[t] = fma(wm, xm[st_of(t)] - ref[st_of(t)], wp * (xp[st_of(t)] - ref[st_of(t)]));
                 T md[NL];
-                if constexpr (sizeof(T) == 8) {
+                if constexpr (sizeof(T) == 8 && UKFB_MEAN1_TRANSPOSE) {
                     // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) factor region:
                     // lane c sums component c over the 16 lanes and publishes the mean
                     constexpr int TS = 18;   // row stride: b128 rows of lanes 0..NL-1 fall on distinct banks

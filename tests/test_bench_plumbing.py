@@ -54,3 +54,10 @@ def test_rank_mismatch_is_an_error():
     out = _run("--gpus", "4", "--plumbing-only", env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                                                         "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_a_failing_rank_fails_the_launcher_and_does_not_hang():
+    """A rank that dies (here: an unknown backend) must take the launcher down with a non-zero exit code, not leave the
+    other ranks waiting in a rendezvous."""
+    out = _run("--gpus", "2", "--backend", "no-such-backend", "--plumbing-only", "--filters", "8")
+    assert out.returncode != 0 and not [l for l in out.stdout.strip().splitlines() if l.startswith("{")]

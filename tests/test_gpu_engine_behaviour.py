@@ -443,3 +443,29 @@ def test_event_stream_cost_follows_events_not_rounds_times_capacity(spe, oracle,
     st_all = eng.status()
     touched = np.zeros(n, dtype=bool); touched[f] = True
     assert (st_all[~touched] == 0).all() and st_or == int(np.bitwise_or.reduce(st_all))
+
+
+@pytest.mark.parametrize("G", [32, 64])
+def test_event_stream_on_the_one_wavefront_per_filter_layout(spe, G):
+    """The indirect per-round launches (filter index list, status OR in the kernel) also exist in the generic kernel
+    (`lanes_per_filter` 32 / 64): the same unordered stream must give the same filters, statuses and last times as
+    the tuned 16-lane layout (different instantiations: equal to rounding, not bit for bit)."""
+    rng = np.random.default_rng(21)
+    n = 37
+    mu, cov = spe.synth.pose_initial(n)
+    E = 150
+    f = rng.integers(0, n, E).astype(np.int64)
+    t = 1_000_000 + rng.integers(1_000, 500_000, E).astype(np.int64)
+    m = rng.choice(np.array([-1, 0, 1, 2, 3, 4, 5, 6, 7, 8], dtype=np.int32), E)
+    z = spe.synth.pose_measurement_for_model(mu[f], np.maximum(m, 0), rng.uniform(-0.02, 0.02, (E, 3)))
+    Q = np.tile(np.eye(3) * 0.0025, (E, 1, 1))
+    out = []
+    for lanes in (16, G):
+        e = spe.BatchPoseUKF(n, lanes_per_filter=lanes); e.initialize(mu, cov)
+        st_or, rounds = e.process_events(f, t, m, z, Q)
+        assert ("ukf_kernel16" in e.last_launch_info()["kernel"]) == (lanes == 16)
+        out.append((e.state(), e.status(), e.last_measurement_time(), st_or, rounds))
+    (ma, ca, _), sa, la, oa, ra = out[0]
+    (mb, cb, _), sb, lb, ob, rb = out[1]
+    assert ra == rb and oa == ob and (sa == sb).all() and (la == lb).all()
+    assert max_abs(ma, mb) <= 1e-9 and max_abs(ca, cb) <= 1e-9

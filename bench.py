@@ -220,7 +220,7 @@ def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):
     from oracle import capi
     sy = spe.synth
     f32 = (lambda x: x.astype(np.float32).astype(np.float64)) if args.precision == "f32" else (lambda x: x)
-    threads = max(1, min(_threads_available(), capi.max_threads()))
+    threads = max(1, min(_threads_available(), capi.max_threads(), 16))   # a GPU box grants about 16 CPUs' worth of time
     m_g, c_g, _ = eng.state(0, sample)
     k0 = 0 if start is None else start[2]
     if orient:

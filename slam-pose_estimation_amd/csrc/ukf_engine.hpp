@@ -50,6 +50,9 @@ struct ukfb_engine {
     double* dt_stage = nullptr;
     int64_t* ts_stage = nullptr;
     uint32_t* reduce_word = nullptr;  // status OR-reduction target
+    // fp32 engines: device scratch for host doubles that are narrowed on the device (grow-only)
+    void* cvt_dev = nullptr;
+    size_t cvt_bytes = 0;
     // ukfb_process_events: device workspace (grow-only)
     void* ev_dev = nullptr;
     size_t ev_bytes = 0;

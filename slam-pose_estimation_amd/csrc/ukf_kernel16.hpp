@@ -7,22 +7,32 @@
 //
 //  * lane l < D owns the sigma PAIR mu [+] (+L col l), mu [+] (-L col l): one L column read and one
 //    SO(3) exp serve both points (exp(-v) = conj(exp(v))); lane D owns the centre point.
-//  * manifold means: 4-step DPP butterfly (quad_perm, quad_perm, row_half_mirror, row_mirror), bit-identical
-//    totals on all 16 lanes; fp64 (12 VALU per butterfly) transposes the 12-wide first iteration through
-//    LDS instead.  Euclidean components converge in the first iteration, later iterations only touch SO(3).
+//  * prediction: only the first NL = 6 tangent components are nonlinear in the state (Pose: position, orientation;
+//    Orient: orientation, velocity).  The affine rest needs no sigma-point sums: its mean is the propagated centre,
+//    its deltas are the signed, scaled factor rows, so Sigma'[affine][affine] = s s Sigma + R in place and the cross
+//    block is (affine factor rows) x (half differences W_l of the nonlinear deltas).  The delta table has 6 columns
+//    and stores U_l = (d+ + d-)/2, d0/sqrt(2), W_l = (d+ - d-)/2: 0.5 sum d d^T = sum over rows of row row^T.
+//  * manifold means over the NL components: fp32 by a 4-step DPP butterfly, fp64 (three instructions per butterfly
+//    step) by two steps + broadcast FMAs of the quad sums, the 6-wide first iteration through an LDS transposition.
+//    Euclidean components converge in the first iteration, later iterations only touch SO(3).  The SO(3) log takes
+//    the known norm of its argument, which buys a half-angle step for one addition (ukf_device.hpp).
 //  * Cholesky: rows in VGPRs; pivot and column entries travel by DPP row_newbcast fused into the FMA
-//    (v_fmac_*_dpp), no LDS inside the factorisation; each column is published once for the consumers.
+//    (v_fmac_*_dpp), no LDS inside the factorisation; the columns are published after the last step.
 //  * gain rows, delta and cross-term rows are exchanged the same way (row_newbcast), not through LDS.
-//  * covariance recombination 0.5 * sum d d^T is blocked into 16 register tiles (2x3 for D = 12,
-//    3x3 for D = 13) reading the delta table from LDS.
+//  * covariance: 16 work items of one register tile each (2x3 for D = 12, 3x3 for D = 13) over the delta table in
+//    LDS -- the tiles of the nonlinear block are shared by two lanes (half the rows each), the cross block has one
+//    lane per tile -- D + 1 iterations for every lane.
 //  * the update exploits exact identities of the unscented transform instead of recomputing them:
 //    (mu [+] d) [-] mu = d for the state deltas; linear (sub-state) measurements have S, Sigma_xz in closed
 //    form; in applyDelta the Euclidean block of 0.5 sum (X_i [-] X_0)(..)^T equals L' L'^T = Sigma' entry for
-//    entry, so only the rows/columns of the SO(3) component are re-sampled (through exp/log).  Results differ
-//    from the literal restatement by rounding only (tests/test_gpu_parity.py holds both to 1e-9 / 1e-4).
+//    entry, so only the rows/columns of the SO(3) component are re-sampled (through exp/log), and the 2 (RT + 3)
+//    signed sigma points that have a rotation part are spread over lanes (one exp / log each).  Results differ
+//    from the literal restatement by rounding only (tests/test_gpu_parity*.py hold both to 1e-9 / 1e-4).
 //  * every per-filter stream is requested in the prologue, before the first dependent instruction.
-//  * LDS per filter: delta table (aliases the factor, the packed-covariance staging and the fp64 mean
-//    transposition) + 136 scalars, row stride 14 (bank-conflict free for lane-strided accesses).
+//  * indirect launches (KArgs::fidx): work item i acts on filter fidx[i]; event streams launch each round over
+//    exactly the filters that have a sample in it.
+//  * LDS per filter (Layout16): factor columns (stride 14) aliased by the delta table and the fp64 transposition,
+//    packed-covariance staging, affine factor rows, 56 scalars of mean / rotation / z, Q / store sink.
 //
 // TOOLCHAIN NOTE (ROCm 7.2 hipcc, -O2/-O3): when this kernel needed VGPR spills / live-range
 // splits, the compiler placed the copies at the join label of a divergent `if` BEFORE the

@@ -219,8 +219,9 @@ template <class T, class M> struct Layout16 {
     static constexpr int MUS = MISC;                        // 16 : mean staging
     static constexpr int ROT = MISC + 16;                   // 12 : rotation matrix of the mean
     static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
-    static constexpr int DUM = MISC + 40;                   // 16 : sink for lane-predicated stores
-    static constexpr int PF_RAW = MISC + 56;
+    static constexpr int NSH = MISC + 40;                   // 24 : shaped process noise of the nonlinear block (21 entries)
+    static constexpr int DUM = MISC + 64;                   // 16 : sink for lane-predicated stores
+    static constexpr int PF_RAW = MISC + 80;
     // the four slices of a wavefront must not start on the same LDS bank (measured: a slice stride that is
     // a multiple of 32 dwords costs 25-50 %: every broadcast read becomes a 4-way conflict)
     static constexpr int PF = PF_RAW + (((PF_RAW * int(sizeof(T)) / 4) % 32 == 0) ? 2 * VEC : 0);
@@ -420,6 +421,17 @@ UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const
     return (M::MODEL == 0 && pin.use_acc) ? vacc : vcv;
 }
 
+// The same for an entry OUTSIDE the two rotated 3x3 diagonal blocks (cross and affine blocks): no rotation.
+template <class T, class M> UKFB_DEV T plain_noise_entry16(const T* Rn, const T* Racc, const ProcIn<T>& pin, int r, int c) {
+    constexpr int D = M::D;
+    const T rn = Rn[r * D + c];
+    if (M::MODEL == 0) {
+        const T vacc = Racc[r * D + c];
+        return pin.use_acc ? vacc : pin.dt * rn;
+    }
+    return (pin.dt * pin.dt) * rn;
+}
+
 // (row, column) of packed lower-triangle entries first .. first + 15, one nibble per entry (entries >= 28 read as 0)
 constexpr unsigned long long tri_rows(int first) {
     unsigned long long t = 0;
@@ -479,6 +491,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     T* MUS = base + LY::MUS;
     T* ROT = base + LY::ROT;
     T* ZQ = base + LY::ZQ;
+    T* NSH = base + LY::NSH;
     T* DUMP = base + LY::DUM;
     const bool has_pair = l < D;       // lane owns the sigma pair of column l
     const bool has_ctr = l == D;       // lane owns the centre point
@@ -855,17 +868,32 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         }
 #pragma unroll
                     for (int t = 0; t < AEL; ++t) anz[t] = Ra[ar[t] * D + ac[t]];
-                } else if (NZ_EARLY) {
+                } else {
+                    // Rotated noise (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85): only the two 3x3 diagonal blocks of
+                    // the nonlinear 6x6 block are rotated.  Its 21 entries are evaluated ONCE per filter, at most two
+                    // per lane, and parked in LDS; the tiles pick them up after the accumulation loop.  (Evaluating the
+                    // rotation for every entry of every tile cost ~200 instructions per wavefront in the Orient cycle.)
 #pragma unroll
-                    for (int i2 = 0; i2 < TR; ++i2)
+                    for (int t = 0; t < 2; ++t) {
+                        const bool v = l + G * t < NL * (NL + 1) / 2;
+                        const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
+                        NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                    }
+                    if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
 #pragma unroll
-                        for (int j2 = 0; j2 < TC; ++j2) {
-                            const int r = R0 + i2, c = C0 + j2;
-                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                            nz[i2][j2] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
-                        }
+                        for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                    for (int t = 0; t < AEL; ++t) anz[t] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, ar[t], ac[t]);
+                            for (int j2 = 0; j2 < TC; ++j2) {
+                                const int r = R0 + i2, c = C0 + j2;
+                                const int rn_ = is_cross ? 0 : r, cn_ = is_cross ? 0 : c;   // a nonlinear tile: rows / columns < NL
+                                T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
+                                keep(shaped);
+                                const T plain = plain_noise_entry16<T, M>(Rn, Ra, pin, r, c);
+                                nz[i2][j2] = is_cross ? plain : shaped;
+                            }
+#pragma unroll
+                        for (int t = 0; t < AEL; ++t) anz[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
+                    }
                 }
             }
 #pragma unroll
@@ -895,7 +923,14 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                         const int r = R0 + i2, c = C0 + j2;
                         const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
                         const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                        const T nv = NZ_EARLY ? nz[i2][j2] : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, rc, cc);
+                        T nv = nz[i2][j2];
+                        if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
+                            const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
+                            T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
+                            keep(shaped);
+                            const T plain = plain_noise_entry16<T, M>(Rn, Ra, pin, rc, cc);
+                            nv = is_cross ? plain : shaped;
+                        }
                         const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
                         PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
                     }
@@ -905,7 +940,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     const int idx = ar[t] * (ar[t] + 1) / 2 + ac[t];
                     T old = PKS[idx];
                     keep(old);
-                    const T nv = NZ_EARLY ? anz[t] : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, ar[t], ac[t]);
+                    const T nv = NZ_EARLY ? anz[t] : plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
                     const T ss = (M::MODEL == 0) ? T(1) : MT<M>::aff_scale(ar[t], pin) * MT<M>::aff_scale(ac[t], pin);
                     PKS[(p_commit && av[t]) ? idx : (LY::DUM - LY::PKS)] = fma(ss, old, nv);
                 }

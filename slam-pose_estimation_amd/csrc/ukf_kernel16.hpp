@@ -464,7 +464,7 @@ constexpr unsigned long long tri_cols(int first) {
 #define UKFB_W64 2
 #endif
 #ifndef UKFB_W32
-#define UKFB_W32 4
+#define UKFB_W32 5
 #endif
 template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W64 : UKFB_W32; }
 

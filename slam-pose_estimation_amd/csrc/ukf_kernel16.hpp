@@ -912,6 +912,23 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
             st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
             {
+                // Orient picks its noise up late: ALL global loads of this lane's entries are issued here, together,
+                // before anything waits for one of them (issued one by one between the stores below they cost a full
+                // L2 round trip each: eleven in a row were 20 % of the Orient wavefront's life)
+                T pl[TR][TC], apl[AEL];
+                if constexpr (!NZ_EARLY) {
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) {
+                            const int r = R0 + i2, c = C0 + j2;
+                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
+                            pl[i2][j2] = plain_noise_entry16<T, M>(Rn, Ra, pin, rc, cc);
+                        }
+#pragma unroll
+                    for (int t = 0; t < AEL; ++t) apl[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
+                    sfence();
+                }
                 // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
                 // (weight 0: its neighbour's accumulators are finite sums of the same filter)
                 const T wsum = is_cross ? T(0) : T(1);
@@ -928,8 +945,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                             const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
                             T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
                             keep(shaped);
-                            const T plain = plain_noise_entry16<T, M>(Rn, Ra, pin, rc, cc);
-                            nv = is_cross ? plain : shaped;
+                            nv = is_cross ? pl[i2][j2] : shaped;
                         }
                         const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
                         PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
@@ -940,7 +956,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     const int idx = ar[t] * (ar[t] + 1) / 2 + ac[t];
                     T old = PKS[idx];
                     keep(old);
-                    const T nv = NZ_EARLY ? anz[t] : plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
+                    const T nv = NZ_EARLY ? anz[t] : apl[t];
                     const T ss = (M::MODEL == 0) ? T(1) : MT<M>::aff_scale(ar[t], pin) * MT<M>::aff_scale(ac[t], pin);
                     PKS[(p_commit && av[t]) ? idx : (LY::DUM - LY::PKS)] = fma(ss, old, nv);
                 }

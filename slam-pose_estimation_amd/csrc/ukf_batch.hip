@@ -45,6 +45,8 @@ template <class T> void convert(const double* src, T* dst, size_t n) {
     for (size_t i = 0; i < n; ++i) dst[i] = T(src[i]);
 }
 
+int ensure_scratch(ukfb_engine* e, size_t bytes);
+
 __global__ void narrow_kernel(const double* src, float* dst, size_t n) {
     const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
     if (i < n) dst[i] = float(src[i]);
@@ -65,13 +67,9 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
     } else {
         // fp32 engine, large array: the doubles cross PCIe as they are and are narrowed on the device (a
         // single-threaded host loop over 12 M values per cycle took ten times longer than the copy)
-        if (e->cvt_bytes < n * sizeof(double)) {
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            if (e->cvt_dev) HIP_TRY(hipFree(e->cvt_dev));
-            e->cvt_dev = nullptr;
-            e->cvt_bytes = 0;
-            HIP_TRY(hipMalloc(&e->cvt_dev, n * sizeof(double)));
-            e->cvt_bytes = n * sizeof(double);
+        {
+            const int rc = ensure_scratch(e, n * sizeof(double));
+            if (rc) return rc;
         }
         HIP_TRY(hipMemcpyAsync(e->cvt_dev, src, n * sizeof(double), hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(narrow_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream,
@@ -82,18 +80,65 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
     return UKFB_OK;
 }
 
+// grow-only device scratch (see ukfb_engine::cvt_dev)
+int ensure_scratch(ukfb_engine* e, size_t bytes) {
+    if (e->cvt_bytes >= bytes) return UKFB_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cvt_dev) HIP_TRY(hipFree(e->cvt_dev));
+    e->cvt_dev = nullptr;
+    e->cvt_bytes = 0;
+    HIP_TRY(hipMalloc(&e->cvt_dev, bytes));
+    e->cvt_bytes = bytes;
+    return UKFB_OK;
+}
+
+// full D x D host covariances (double, row-major) <-> the engine's packed lower triangle (precision T), on the device:
+// one thread per scalar.  Replaces single-threaded host loops over count * D * D values in initialize / get_state.
+template <class T> __global__ void pack_cov_kernel(const double* full, T* packed, int64_t count, int D, int PK) {
+    const int64_t gid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (gid >= count * PK) return;
+    const int64_t i = gid / PK;
+    const int e = int(gid % PK);
+    int r = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
+    if (r * (r + 1) / 2 > e) --r;
+    if ((r + 1) * (r + 2) / 2 <= e) ++r;
+    const int c = e - r * (r + 1) / 2;
+    packed[gid] = T(full[i * D * D + r * D + c]);          // the lower triangle is what Eigen's LLT reads
+}
+template <class T> __global__ void unpack_cov_kernel(const T* packed, double* full, int64_t count, int D, int PK) {
+    const int64_t gid = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (gid >= count * D * D) return;
+    const int64_t i = gid / (int64_t(D) * D);
+    const int rc = int(gid % (int64_t(D) * D)), r = rc / D, c = rc % D;
+    const int hi = r > c ? r : c, lo = r > c ? c : r;
+    full[gid] = double(packed[i * PK + hi * (hi + 1) / 2 + lo]);
+}
+__global__ void widen_kernel(const float* src, double* dst, size_t n) {
+    const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (i < n) dst[i] = double(src[i]);
+}
+constexpr int64_t COV_CHUNK = 65536;   // filters per pack / unpack pass (75 MB of scratch for D = 12)
+
 int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* dst, size_t n) {
     if (n == 0) return UKFB_OK;
     if (e->prec == UKFB_F64) {
         HIP_TRY(hipMemcpyAsync(dst, static_cast<const double*>(src_dev) + elem_offset, n * sizeof(double),
                                hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-    } else {
+    } else if (n < 16384) {
         std::vector<float> tmp(n);
         HIP_TRY(hipMemcpyAsync(tmp.data(), static_cast<const float*>(src_dev) + elem_offset, n * sizeof(float),
                                hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (size_t i = 0; i < n; ++i) dst[i] = double(tmp[i]);
+    } else {   // fp32 engine, large array: widened on the device, the doubles cross PCIe as they are
+        int rc = ensure_scratch(e, n * sizeof(double));
+        if (rc) return rc;
+        hipLaunchKernelGGL(widen_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream,
+                           static_cast<const float*>(src_dev) + elem_offset, static_cast<double*>(e->cvt_dev), n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dst, e->cvt_dev, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
     }
     return UKFB_OK;
 }
@@ -510,17 +555,25 @@ int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* 
     if (!range_ok(e, first, count) || !mu || !cov) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_initialize: bad range");
     HIP_TRY(hipSetDevice(e->device));
     const int D = e->D, PK = e->PK;
-    std::vector<double> packed(size_t(count) * PK);
-    for (int64_t i = 0; i < count; ++i) {
-        const double* c = cov + size_t(i) * D * D;
-        double* p = packed.data() + size_t(i) * PK;
-        for (int r = 0; r < D; ++r)
-            for (int k = 0; k <= r; ++k) p[r * (r + 1) / 2 + k] = c[r * D + k];
-    }
     int rc = upload(e, e->mu, size_t(first) * e->S, mu, size_t(count) * e->S);
     if (rc) return rc;
-    rc = upload(e, e->cov, size_t(first) * PK, packed.data(), size_t(count) * PK);
-    if (rc) return rc;
+    // covariances: the full matrices cross PCIe as they are, the packing (and narrowing) runs on the device
+    for (int64_t lo = 0; lo < count; lo += COV_CHUNK) {
+        const int64_t m = std::min(COV_CHUNK, count - lo);
+        const size_t nfull = size_t(m) * D * D;
+        rc = ensure_scratch(e, nfull * sizeof(double));
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(e->cvt_dev, cov + size_t(lo) * D * D, nfull * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        const unsigned blocks = unsigned((size_t(m) * PK + 255) / 256);
+        if (e->prec == UKFB_F64)
+            hipLaunchKernelGGL(pack_cov_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->cvt_dev),
+                               static_cast<double*>(e->cov) + size_t(first + lo) * PK, m, D, PK);
+        else
+            hipLaunchKernelGGL(pack_cov_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->cvt_dev),
+                               static_cast<float*>(e->cov) + size_t(first + lo) * PK, m, D, PK);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(e->stream));   // the scratch is reused by the next chunk
+    }
     HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
     HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -536,15 +589,22 @@ int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, dou
         rc = download(e, e->mu, size_t(first) * e->S, mu, size_t(count) * e->S);
         if (rc) return rc;
     }
-    if (cov) {
-        std::vector<double> packed(size_t(count) * PK);
-        rc = download(e, e->cov, size_t(first) * PK, packed.data(), size_t(count) * PK);
-        if (rc) return rc;
-        for (int64_t i = 0; i < count; ++i) {
-            double* c = cov + size_t(i) * D * D;
-            const double* p = packed.data() + size_t(i) * PK;
-            for (int r = 0; r < D; ++r)
-                for (int k = 0; k <= r; ++k) c[r * D + k] = c[k * D + r] = p[r * (r + 1) / 2 + k];
+    if (cov) {   // mirrored to full matrices (and widened) on the device, chunk by chunk
+        for (int64_t lo = 0; lo < count; lo += COV_CHUNK) {
+            const int64_t m = std::min(COV_CHUNK, count - lo);
+            const size_t nfull = size_t(m) * D * D;
+            rc = ensure_scratch(e, nfull * sizeof(double));
+            if (rc) return rc;
+            const unsigned blocks = unsigned((nfull + 255) / 256);
+            if (e->prec == UKFB_F64)
+                hipLaunchKernelGGL(unpack_cov_kernel<double>, dim3(blocks), dim3(256), 0, e->stream,
+                                   static_cast<const double*>(e->cov) + size_t(first + lo) * PK, static_cast<double*>(e->cvt_dev), m, D, PK);
+            else
+                hipLaunchKernelGGL(unpack_cov_kernel<float>, dim3(blocks), dim3(256), 0, e->stream,
+                                   static_cast<const float*>(e->cov) + size_t(first + lo) * PK, static_cast<double*>(e->cvt_dev), m, D, PK);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(cov + size_t(lo) * D * D, e->cvt_dev, nfull * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
         }
     }
     if (initialised) {

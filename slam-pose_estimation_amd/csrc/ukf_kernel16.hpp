@@ -214,14 +214,20 @@ template <class T, class M> struct Layout16 {
     // delta table rows 0..N-1 alias the factor (dead once every lane holds its column); its zero row lies behind it
     static constexpr int TNL = (D * LS > N * ST) ? (D * LS - N * ST) : 0;
     static constexpr int PKS = al(TNL + (N + 1) * ST);      // PKP  : packed covariance staging (survives the prediction)
-    static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor
-    static constexpr int MISC = LAF + al((D + 1) * ST);
-    static constexpr int MUS = MISC;                        // 16 : mean staging
-    static constexpr int ROT = MISC + 16;                   // 12 : rotation matrix of the mean
-    static constexpr int ZQ = MISC + 28;                    // 12 : z (3) + Q (9)
-    static constexpr int NSH = MISC + 40;                   // 24 : shaped process noise of the nonlinear block (21 entries)
-    static constexpr int DUM = MISC + 64;                   // 16 : sink for lane-predicated stores
-    static constexpr int PF_RAW = MISC + 80;
+    static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor.  Where !LAF_ROW_D its zero row D
+                                                            // (read by the cross lanes in their last trip) is not stored: it aliases the
+                                                            // mean staging behind it - finite values that meet the table's exact-zero row
+    static constexpr bool LAF_ROW_D = !(M::MODEL == 0 && sizeof(T) == 8);   // only the fp64 Pose slice needs the trim
+    static constexpr int MISC = LAF + al((D + (LAF_ROW_D ? 1 : 0)) * ST);
+    static constexpr int MUS = MISC;                        // S  : mean staging
+    static constexpr int ROT = MUS + al(S);                 // 9  : rotation matrix of the mean
+    static constexpr int ZQ = ROT + al(9);                  // 12 : z (3) + Q (9)
+    static constexpr int NSH = ZQ + 12;                     // 21 : shaped process noise of the nonlinear block
+    static constexpr int DUM = NSH + al(21);                // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
+    static constexpr int PF_RAW = DUM + al(S);
+    // Workgroups per CU follow the LDS allocation granule of 1280 B (measured, tools/lds_granule.hip; the occupancy API
+    // assumes 512 B): the fp64 Pose slice must stay <= 12800 B per workgroup for 12 workgroups = 3 wavefronts per SIMD
+    // (it was 13120 B = 11 workgroups per CU until round 2).
     // the four slices of a wavefront must not start on the same LDS bank (measured: a slice stride that is
     // a multiple of 32 dwords costs 25-50 %: every broadcast read becomes a 4-way conflict)
     static constexpr int PF = PF_RAW + (((PF_RAW * int(sizeof(T)) / 4) % 32 == 0) ? 2 * VEC : 0);
@@ -650,8 +656,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
                 {   // affine rows of this lane's column, scaled by the model's diagonal factor, for the cross block;
-                    // lanes without a column hold zeros and fill the table's zero row
-                    T* lrow = LAF + ((l < D) ? l : D) * ST;
+                    // lanes without a column hold zeros: they fill LAF's zero row, or go to the sink where that row is
+                    // not stored (Layout16::LAF_ROW_D)
+                    T* lrow = LY::LAF_ROW_D ? (LAF + ((l < D) ? l : D) * ST) : ((l < D) ? (LAF + l * ST) : DUMP);
 #pragma unroll
                     for (int c = NL; c < D; ++c) lrow[c - NL] = (M::MODEL == 0) ? col[c] : col[c] * MT<M>::aff_scale(c, pin);
                 }

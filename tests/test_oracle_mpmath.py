@@ -323,3 +323,25 @@ def test_pose_orientation_update_on_so3_against_40_digits(spe, oracle):
         zq = so3_exp(to_mp(z[i]))
         mu2, cu2 = mp_update_so3(POSE, to_mp(mu[i]), to_mp(cov[i]), zq, to_mp(Q[i]), lambda x: x[3:7], tol)
         assert max_abs(to_np(mu2), m_u[i]) < 1e-13 and max_abs(to_np(cu2), c_u[i]) < 1e-13
+
+
+def test_rotation_delta_rebase_series_against_40_digits():
+    """The engine's final rotation deltas (ukf_device.hpp so3_rebase_small): log(exp(-a) exp(d)) to first order in the last,
+    sub-tolerance move a of the mean and to all orders in the delta d.  Bounds the kernel guarantees before it uses the
+    series: |d|^2 <= 4, |a|^2 <= 1e-12.  Storage order x y z w as everywhere in this file."""
+    rng = np.random.default_rng(11)
+    coef = [1 / 12., 1 / 720., 1 / 30240., 1 / 1209600., 1 / 47900160., 691 / 1307674368000.]
+    worst = 0.0
+    for trial in range(400):
+        d = rng.uniform(-1, 1, 3)
+        d *= rng.uniform(0.0, 2.0) / np.linalg.norm(d)
+        a = rng.uniform(-1, 1, 3)
+        a *= 10.0 ** rng.uniform(-9, -6) / np.linalg.norm(a)
+        exact = so3_log(qmul(so3_exp([mp.mpf(-x) for x in a]), so3_exp([mp.mpf(x) for x in d])))
+        t, da = float(d @ d), float(d @ a)
+        c = 0.0
+        for k in reversed(coef):
+            c = c * t + k
+        approx = d * (1 - c * da) - a * (1 - c * t) - 0.5 * np.cross(a, d)
+        worst = max(worst, max(abs(float(exact[k]) - approx[k]) for k in range(3)))
+    assert worst < 1e-12, worst

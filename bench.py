@@ -511,6 +511,12 @@ def run_rank(args):
                     "issue_cycles_per_inst": cyc, "clock_mhz": pmc_e["clock_mhz"], "simds": N_SIMD,
                     "achieved": need / (kernel_ms * 1e-3) / 1e12, "peak": N_SIMD * clock_hz / 1e12,
                     "unit": "T issue-cycles/s", "frac": need / have, "source": pmc_e.get("source")}
+            if pmc_e.get("issue_cycles_per_wave_weighted"):
+                # the same with the per-class issue costs measured on this chip (tools/valu_tput.hip): selects, compares,
+                # DPP, 64-bit and SGPR-operand instructions take 4 cycles also in fp32, transcendentals 6.5 / 13
+                wneed = float(pmc_e["issue_cycles_per_wave_weighted"]) * waves
+                valu["issue_cycles_per_wave_weighted"] = pmc_e["issue_cycles_per_wave_weighted"]
+                valu["frac_weighted"] = wneed / have
         out = {
             "metric": "UKF predict+update filter-cycles/s, " + ("OrientationState" if orient else "PoseWithVelocity") + " filters",
             "value": value,

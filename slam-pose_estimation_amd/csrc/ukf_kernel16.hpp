@@ -247,6 +247,17 @@ template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layo
 // scheduling fence: keeps the machine scheduler from hoisting the next phase's loads / ALU work
 // across this point (it otherwise trades ~2x the registers for ILP and ends up spilling)
 UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
+// Issue priority of the wavefront (s_setprio): the factorisations are serial dependency chains; a wavefront inside one should
+// not queue behind the throughput-bound phases of its SIMD neighbours.
+// Measured (same-box A/B, 300 steps): priority 1 inside the two factorisations +0.8 % fp64, +2.5..3 % fp32; raising the mean
+// iteration or the whole update as well brought nothing more.
+#ifndef UKFB_CHOL_PRIO
+#define UKFB_CHOL_PRIO 1
+#endif
+#define UKFB_PRIO(p)                                            \
+    do {                                                        \
+        if constexpr (UKFB_CHOL_PRIO != 0) __builtin_amdgcn_s_setprio(p); \
+    } while (0)
 // Phase markers (diagnostic builds only; the product build defines neither macro and they vanish):
 //   -DUKFB_PHASE_MARKS  an assembly comment between two scheduling barriers, read by tools/isa_phases.py
 //   -DUKFB_STAMPS       lane 0 stores s_memtime to KArgs::stamps[workgroup][marker] (tools/phase_stamps.sh:
@@ -659,7 +670,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     UKFB_MARK("p_chol_row");
                     load_row<T, D>(PKS, l, arow);
                     UKFB_MARK("p_chol_fact");
+                    UKFB_PRIO(UKFB_CHOL_PRIO);
                     rs = chol16<T, D, LS>(arow, Lc, l, ok);
+                    UKFB_PRIO(0);
                     wsync();
                 }
                 UKFB_MARK("p_sigma");
@@ -1109,7 +1122,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     // Only the first ZCOLS columns of the factor move the measurement.  An indefinite Sigma whose
                     // first ZCOLS pivots are positive is caught by the complete factorisation of Sigma' below
                     // (Sigma' <= Sigma), with the same status bit.
+                    UKFB_PRIO(UKFB_CHOL_PRIO);
                     rs = chol16<T, D, LS, MT<M>::ZCOLS>(arow, Lc, l, okg);
+                    UKFB_PRIO(0);
                     wsync();
                 }
                 T zp[4], zm[4], z0[4];
@@ -1291,7 +1306,9 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     srow2[b] = arow2[b];
                     d0[b] = row_bcast<b>(del);
                 });
+                UKFB_PRIO(UKFB_CHOL_PRIO);
                 rs2 = chol16<T, D, LS, D, RT + 3>(arow2, Lc, l, ok2);   // applyDelta reads the first RT + 3 columns only
+                UKFB_PRIO(0);
                 wsync();
             }
             sfence();

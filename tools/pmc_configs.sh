@@ -3,6 +3,7 @@
 #   - FETCH_SIZE and WRITE_SIZE in separate passes, corrected with factors calibrated on the engine's own access
 #     pattern (tools/calib_traffic.hip; MI355X_MICROARCH.md: FETCH_SIZE halves wide coalesced reads on gfx950)
 #   - one SQ/GRBM pass: VALU wave-instructions, VALU busy quad-cycles, wave cycles, GRBM_GUI_ACTIVE (clock)
+#   - two SQ passes: VALU instructions by class (FMA / MUL / ADD / TRANS per precision, INT32, INT64, CVT) for the weighted issue model
 #   - rocprofv3 --kernel-trace --stats of the default bench command
 # Output: gpurun_out/pmc_configs/{traffic_latest.json,pmc_latest.json,*_kernel_stats.csv,summary.txt}
 # usage: tools/pmc_configs.sh [tag]        (copy the json / csv files into profiles/ afterwards)
@@ -19,7 +20,9 @@ done
 B="--steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-extra-regions"
 cfg() {  # name, bench args
   name=$1; shift
-  for pass in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  for pass in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+      "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT" \
+      "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU"; do
     p=$(echo $pass | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/${name}_$p -- python3 bench.py $B "$@" > $out/${name}_$p.json 2> $out/${name}_$p.err
     echo "$name $p rc=$?"

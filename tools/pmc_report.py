@@ -32,6 +32,10 @@ def kernel_ns(d, kernel_substr):
     return sum(vals) / len(vals) if vals else None
 
 
+# DPP-fused fp32 arithmetic on the default path of each kernel (static listing, tools/isa_phases.py -DUKFB_ASSUME_HEADLINE):
+# the SQ counts them as FMA / ADD, the SIMD issues them at the 4-cycle rate
+DPP_FUSED_F32 = {"ukf_kernel16<f32,pose,cycle>": 243.0, "ukf_kernel16<f32,orient,cycle>": 300.0}
+
 calib = {}
 for prec in ("f64", "f32"):
     known = json.loads(open(os.path.join(out, f"calib_{prec}_FETCH_SIZE.json")).read().strip().splitlines()[-1])["bytes_per_launch"]
@@ -67,7 +71,29 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5"):
     grbm = mean_counter(d, "GRBM_GUI_ACTIVE", "ukf_kernel")
     ns = kernel_ns(d, "ukf_kernel")
     clock_mhz = grbm / 8.0 / (ns * 1e-9) / 1e6
+    # instruction classes (two more passes) -> issue cycles per wave with the per-class costs measured by tools/valu_tput.hip
+    # and tools/gen_valu_tput2.py on this chip (profiles/r02_valu_throughput_*.txt): a wave64 instruction occupies the SIMD for
+    # 4 cycles when it is fp64, DPP, 64-bit, a select / compare / shift / 3-operand integer or reads an SGPR; 2 cycles when
+    # it is a plain fp32 FMA / MUL / ADD or v_mov_b32; ~2.7 for and / or / add_u32; 6.5 (fp32) / 13 (fp64) for rcp / rsq / sqrt
+    cls = {}
+    for cname in ("FMA_F32", "MUL_F32", "ADD_F32", "TRANS_F32", "INT32", "CVT", "FMA_F64", "MUL_F64", "ADD_F64", "TRANS_F64", "INT64"):
+        dd = f"{name}_SQ_INSTS_VALU_FMA_F32" if cname in ("FMA_F32", "MUL_F32", "ADD_F32", "TRANS_F32", "INT32", "CVT") else f"{name}_SQ_INSTS_VALU_FMA_F64"
+        v = mean_counter(dd, "SQ_INSTS_VALU_" + cname, "ukf_kernel")
+        cls[cname] = (v / waves) if v is not None else None
+    weighted = None
+    if all(v is not None for v in cls.values()):
+        per_wave = valu / waves
+        fp32 = cls["FMA_F32"] + cls["MUL_F32"] + cls["ADD_F32"]
+        fp64 = cls["FMA_F64"] + cls["MUL_F64"] + cls["ADD_F64"]
+        other = per_wave - fp32 - fp64 - cls["TRANS_F32"] - cls["TRANS_F64"] - cls["INT32"] - cls["INT64"] - cls["CVT"]
+        dpp_fused = DPP_FUSED_F32.get(kern, 0.0) if prec == "f32" else 0.0    # counted as FMA / ADD by the SQ, issue like fp64
+        weighted = (2.0 * fp32 + 2.0 * dpp_fused + 4.0 * fp64 + 6.5 * cls["TRANS_F32"] + 13.0 * cls["TRANS_F64"] + 3.3 * cls["INT32"]
+                    + 4.0 * cls["INT64"] + 4.0 * cls["CVT"] + 3.5 * other)
+        cls["other(mov,select,compare,dpp mov)"] = other
+        cls["dpp_fused_fp32_static"] = dpp_fused
     e = {"config": name, "kernel": kern, "filters_per_launch": n, "precision": prec,
+         "valu_classes_per_wave": cls, "issue_cycles_per_wave_weighted": weighted,
+         "valu_issue_frac_weighted_in_pass": (weighted * waves / (1024 * clock_mhz * 1e6 * ns * 1e-9)) if weighted else None,
          "valu_insts_per_wave": valu / waves, "lds_insts_per_wave": lds / waves,
          # issue cost of one wave64 VALU instruction on a SIMD (MI355X_MICROARCH.md, cycle constants): fp64 moves 16 lanes
          # per cycle = 4 cycles; fp32 sustains one instruction per 2 cycles when several waves interleave
@@ -80,7 +106,8 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5"):
     pmc.append(e)
     lines.append(f"{name:13s} {kern:34s} n={n:8d} traffic {hbm / 1e9:7.3f} GB/launch (alg {bench['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f}) "
                  f"VALU/wave {e['valu_insts_per_wave']:.0f} LDS/wave {e['lds_insts_per_wave']:.0f} cyc/inst {e['issue_cycles_per_valu_inst']:.0f} "
-                 f"clock {clock_mhz:.0f} MHz kernel {ns * 1e-6:.3f} ms VALU issue frac {e['valu_issue_frac_in_pass']:.3f}")
+                 f"clock {clock_mhz:.0f} MHz kernel {ns * 1e-6:.3f} ms VALU issue frac {e['valu_issue_frac_in_pass']:.3f}"
+                 + (f" weighted {e['valu_issue_frac_weighted_in_pass']:.3f} ({weighted:.0f} cycles/wave)" if weighted else ""))
 json.dump({"note": "HBM bytes per launch of the fused kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), corrected with "
                    "factors calibrated on the engine's own access pattern (tools/calib_traffic.hip, tools/pmc_configs.sh)",
            "entries": traffic}, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)

@@ -844,18 +844,18 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             UKFB_MARK("p_delta_r");
             {   // rotation deltas to the final mean; quaternion of the mean.  The loop's last trip took the logarithms
                 // against the reference BEFORE its (sub-tolerance) move al: re-base them to first order in al, exact in
-                // the delta (error < 3e-13 under the bounds tested here); anything else takes the logarithms again.
+                // the delta (remainder < 4e-14 under the bounds tested here); anything else takes the logarithms again.
                 T rp[3], rm[3];
                 bool rebase = have_last;
+                const T a2 = al[0] * al[0] + al[1] * al[1] + al[2] * al[2];
                 if (rebase) {
                     const T tp = rpl[0] * rpl[0] + rpl[1] * rpl[1] + rpl[2] * rpl[2];
                     const T tm = rml[0] * rml[0] + rml[1] * rml[1] + rml[2] * rml[2];
-                    const T a2 = al[0] * al[0] + al[1] * al[1] + al[2] * al[2];
-                    rebase = wave_all(tp <= T(4) && tm <= T(4) && a2 <= T(1e-12));
+                    rebase = wave_all(tp <= T(2.25) && tm <= T(2.25) && a2 <= T(1e-12));
                 }
                 if (rebase) {
-                    so3_rebase_small(rpl, al, rp);
-                    so3_rebase_small(rml, al, rm);
+                    so3_rebase_small(rpl, al, a2, rp);
+                    so3_rebase_small(rml, al, a2, rm);
                 } else {
                     rot_minus_n(qp, qr, qn2, rp);
                     rot_minus_n(qm, qr, qn2, rm);

@@ -326,22 +326,23 @@ def test_pose_orientation_update_on_so3_against_40_digits(spe, oracle):
 
 
 def test_rotation_delta_rebase_series_against_40_digits():
-    """The engine's final rotation deltas (ukf_device.hpp so3_rebase_small): log(exp(-a) exp(d)) to first order in the last,
-    sub-tolerance move a of the mean and to all orders in the delta d.  Bounds the kernel guarantees before it uses the
-    series: |d|^2 <= 4, |a|^2 <= 1e-12.  Storage order x y z w as everywhere in this file."""
+    """The engine's final rotation deltas (ukf_device.hpp so3_rebase_small): log(exp(-a) exp(d)) by one Euler step of the
+    inverse left Jacobian (exact in the delta d) plus the leading second-order term in the last, sub-tolerance move a of the
+    mean.  Bounds the kernel guarantees before it uses the formula: |d|^2 <= 2.25, |a|^2 <= 1e-12.  Storage order x y z w as
+    everywhere in this file."""
     rng = np.random.default_rng(11)
     coef = [1 / 12., 1 / 720., 1 / 30240., 1 / 1209600., 1 / 47900160., 691 / 1307674368000.]
     worst = 0.0
     for trial in range(400):
         d = rng.uniform(-1, 1, 3)
-        d *= rng.uniform(0.0, 2.0) / np.linalg.norm(d)
+        d *= rng.uniform(0.0, 1.5) / np.linalg.norm(d)
         a = rng.uniform(-1, 1, 3)
         a *= 10.0 ** rng.uniform(-9, -6) / np.linalg.norm(a)
         exact = so3_log(qmul(so3_exp([mp.mpf(-x) for x in a]), so3_exp([mp.mpf(x) for x in d])))
-        t, da = float(d @ d), float(d @ a)
+        t, da, a2 = float(d @ d), float(d @ a), float(a @ a)
         c = 0.0
         for k in reversed(coef):
             c = c * t + k
-        approx = d * (1 - c * da) - a * (1 - c * t) - 0.5 * np.cross(a, d)
-        worst = max(worst, max(abs(float(exact[k]) - approx[k]) for k in range(3)))
-    assert worst < 1e-12, worst
+        shift = -d * (c * da + a2 / 12) - a * (1 - c * t - da / 12) - 0.5 * np.cross(a, d)   # approx - d
+        worst = max(worst, max(abs(float(exact[k] - mp.mpf(d[k])) - shift[k]) for k in range(3)))
+    assert worst < 4e-14, worst

@@ -98,11 +98,38 @@ template <class T, int N> UKFB_DEV T horner(const T (&c)[N + 1], T x) {
     for (int k = N - 1; k >= 0; --k) r = fma(r, x, c[k]);
     return r;
 }
+// fp32: the coefficients as instruction literals (v_fmaak_f32, 2 issue cycles).  Read through the array they arrive by scalar
+// loads and every Horner step carries an SGPR operand, which issues at the 4-cycle rate on gfx950; in fp64 the
+// SGPR pairs are the cheapest form (a 64-bit literal needs two s_mov per use).
+#define UKFB_HORNER_LIT(ARR, N, x, r)                                   \
+    do {                                                                \
+        constexpr float c_[5] = {ARR[0], ARR[1], ARR[2], ARR[3], (N >= 4 ? ARR[N >= 4 ? 4 : 0] : 0.f)}; \
+        r = c_[N];                                                      \
+        if constexpr (N >= 4) r = fma(r, x, c_[3]);                     \
+        r = fma(r, x, c_[2]);                                           \
+        r = fma(r, x, c_[1]);                                           \
+        r = fma(r, x, c_[0]);                                           \
+    } while (0)
 template <class T> UKFB_DEV void poly_cos_sinc(T y, T& c, T& s) {
-    c = horner<T, Poly<T>::NC>(Poly<T>::COS, y);
-    s = horner<T, Poly<T>::NS>(Poly<T>::SINC, y);
+    if constexpr (sizeof(T) == 4) {
+        static_assert(Poly<float>::NC == 4 && Poly<float>::NS == 3, "literal Horner forms");
+        UKFB_HORNER_LIT(Poly<float>::COS, 4, y, c);
+        UKFB_HORNER_LIT(Poly<float>::SINC, 3, y, s);
+    } else {
+        c = horner<T, Poly<T>::NC>(Poly<T>::COS, y);
+        s = horner<T, Poly<T>::NS>(Poly<T>::SINC, y);
+    }
 }
-template <class T> UKFB_DEV T poly_atan_ratio(T u) { return horner<T, Poly<T>::NA>(Poly<T>::ATAN, u); }
+template <class T> UKFB_DEV T poly_atan_ratio(T u) {
+    if constexpr (sizeof(T) == 4) {
+        static_assert(Poly<float>::NA == 3, "literal Horner form");
+        T r;
+        UKFB_HORNER_LIT(Poly<float>::ATAN, 3, u, r);
+        return r;
+    } else {
+        return horner<T, Poly<T>::NA>(Poly<T>::ATAN, u);
+    }
+}
 
 template <class T> struct TwoPi;
 template <> struct TwoPi<double> {

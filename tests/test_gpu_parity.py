@@ -182,3 +182,36 @@ def test_large_rotations_take_the_fallback_paths(spe, oracle):
     assert (e.status() == st_o2).all()
     scale = max(1.0, float(np.abs(c_o2).max()))
     assert max_abs(m_g2, m_o2) <= 1e-7 and max_abs(c_g2, c_o2) <= 1e-7 * scale
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_predict_mean_iteration_exit_paths(spe, oracle, prec):
+    """The three ways the prediction obtains its final rotation deltas (ukf_kernel16.hpp, p_delta_r), alone and mixed inside
+    one wavefront (4 consecutive filters): (a) tiny covariance, the first mean step is already below the tolerance and the
+    iteration loop never runs -> logarithms against the final mean; (b) ordinary spread -> the loop's last logarithms
+    re-based by so3_rebase_small; (c) orientation sigma 1.2 rad, deltas beyond the 1.5 rad bound of the series ->
+    logarithms again.  ukfom's iteration and the final boxminus are what is being matched."""
+    n = 96
+    mu, cov = spe.synth.pose_initial(n)
+    kind = np.arange(n) % 3                      # neighbours differ: every wavefront holds a mixture ...
+    kind[:32] = np.repeat([0, 1, 2], 12)[:32]    # ... except the first eight, which are (mostly) uniform
+    for i in range(n):
+        if kind[i] == 0:
+            cov[i] *= 1e-10
+        elif kind[i] == 2:
+            cov[i, 3:6, :] *= 24.0
+            cov[i, :, 3:6] *= 24.0               # orientation sigma 0.05 -> 1.2 rad
+    eng = spe.BatchPoseUKF(n, precision=prec)
+    eng.initialize(mu, cov)
+    acc, _, _ = spe.synth.pose_cycle_inputs(n, 0, mu[:, :3])
+    acc_cov = 0.01 * np.eye(3)
+    eng.set_acceleration(acc, acc_cov)
+    eng.predict(0.01)
+    m_g, c_g, _ = eng.state()
+    R = spe.synth.pose_default_process_noise()
+    m_o, c_o, st_o = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
+    assert (eng.status() == st_o).all()
+    wide = kind == 2
+    assert max_abs(m_g[~wide], m_o[~wide]) <= TOL[prec] and max_abs(c_g[~wide], c_o[~wide]) <= TOL[prec]
+    scale = max(1.0, float(np.abs(c_o[wide]).max()))     # ill-conditioned by construction: relative to the covariance's size
+    assert max_abs(m_g[wide], m_o[wide]) <= 10 * TOL[prec] and max_abs(c_g[wide], c_o[wide]) <= 10 * TOL[prec] * scale

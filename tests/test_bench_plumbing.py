@@ -61,3 +61,24 @@ def test_a_failing_rank_fails_the_launcher_and_does_not_hang():
     other ranks waiting in a rendezvous."""
     out = _run("--gpus", "2", "--backend", "no-such-backend", "--plumbing-only", "--filters", "8")
     assert out.returncode != 0 and not [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(400)
+def test_under_torch_distributed_run_every_process_is_a_rank():
+    """The driver's own N > 1 command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`.  RANK is set, so bench.py must NOT start children again; rank 0 prints
+    the one JSON line, the other ranks print nothing."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--backend", "gloo", "--plumbing-only", "--filters", "64"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["plumbing_only"] is True and d["backend"] == "gloo" and d["config"]["filters_per_gpu"] == 32

@@ -290,3 +290,18 @@ def test_full_size_config5_mixed_fp64(spe, oracle):
     m_o, c_o, s2 = oracle.pose_update(m_o, c_o, keep["models"], keep["z"], keep["Q"], threads=8)
     assert (s1 == 0).all() and (st[:2048] == s2).all()
     assert max_abs(m_f[:2048], m_o) <= 1e-9 and max_abs(c_f[:2048], c_o) <= 1e-9
+
+
+def test_randomised_scenarios_against_the_oracle():
+    """tools/fuzz_parity.py: batch sizes 1..256 (ragged wavefronts), both precisions, covariance scales over six decades, spins,
+    time steps, missing accelerations, per-filter models with inactive filters, random SPD measurement covariances, optional
+    Mahalanobis gate; separate launches and the fused cycle, Pose and Orient; state, covariance and status after every launch."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fails = fz.run(120, 7)
+    assert not fails, fails[:3]
+    assert fz.LAUNCHES[0] > 400 and 0 < fz.WORST[0] < 1 and 0 < fz.WORST[1] < 1

@@ -655,6 +655,16 @@ int ukfb_set_process_noise(ukfb_engine* e, const double* R) {
     HIP_TRY(hipSetDevice(e->device));
     const size_t dd = size_t(e->D) * e->D;
     e->Rn_host.assign(R, R + dd);
+    {   // blocks [0:3,0:3] and [3:6,3:6] are the ones predictionStepImpl rotates (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85)
+        bool iso = true;
+        for (int b = 0; b < 6; b += 3)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    const double v = R[size_t(b + r) * e->D + (b + c)];
+                    iso = iso && (r == c ? v == R[size_t(b) * e->D + b] : v == 0.0);
+                }
+        e->noise_iso = iso;
+    }
     if (e->Rn_per_filter) {
         std::vector<double> all(size_t(e->cap) * dd);
         for (int64_t i = 0; i < e->cap; ++i) std::memcpy(all.data() + size_t(i) * dd, R, dd * sizeof(double));

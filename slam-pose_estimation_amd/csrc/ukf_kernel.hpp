@@ -43,6 +43,8 @@ template <class T> struct KArgs {
     // A filter must not appear twice in one launch.
     const int32_t* fidx;
     int status_accumulate;       // != 0: OR the new status word into the stored one instead of replacing it
+    int noise_iso;               // != 0: the two 3x3 diagonal noise blocks that the models rotate are multiples of the identity
+                                 // (batch-uniform noise only) -- R s I R^T = s I, the rotation is skipped (ukf_kernel16.hpp)
     T* mu;                       // [filters][S]
     T* cov;                      // [n][PK] packed lower triangle, row-major
     uint32_t* status;            // [n]

@@ -648,15 +648,23 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             constexpr auto st_of = [](int t) constexpr { return t < MT<M>::RT ? t : t + 1; };
             T xp[S], xm[S], ref[S];
             bool ok;
+            bool noise_plain = false;   // wave-uniform: the process noise needs no rotation (see below)
             T qn2;   // |q|^2 of the mean's orientation = norm of every conj(a) * b between sigma-point orientations
             {
                 T mu_r[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
                 qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
-                // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose
-                // acceleration branch does not rotate its noise (wave-uniform skip)
-                if (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc))) {
+                // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose acceleration branch does
+                // not rotate its noise (wave-uniform skip).  An isotropic block is its own rotation (R s I R^T = s I R R^T): with
+                // the launch-wide flag set by the host and unit orientation quaternions (|q|^2 within 1e-9 of 1 on every lane,
+                // 1e-4 in fp32 where the norm drifts; R R^T = I up to that) neither the rotation matrix nor the rotated entries
+                // are evaluated, the shaped-noise table is filled with the plain entries instead
+                // (OrientationState kernels only: in the Pose kernels the two extra branches cost the acceleration-branch
+                // headline 0.6 % through code placement alone, same-box A/B)
+                if constexpr (M::MODEL != 0)
+                    noise_plain = a.noise_iso != 0 && wave_all(m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(1e-4)));
+                if (!noise_plain && (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc)))) {
                     T q[4], rot[9];
                     M::orientation(mu_r, q);
                     quat_to_matrix(q, rot);
@@ -932,7 +940,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     for (int t = 0; t < 2; ++t) {
                         const bool v = l + G * t < NL * (NL + 1) / 2;
                         const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
-                        NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                        // (isotropic blocks, noise_plain: the table entry itself, no rotation and no rotation matrix)
+                        const T ne = (M::MODEL != 0 && noise_plain) ? plain_noise_entry16<T, M>(Rn, Ra, pin, r, c)
+                                                                    : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                        NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = ne;
                     }
                     if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
 #pragma unroll

@@ -215,3 +215,54 @@ def test_predict_mean_iteration_exit_paths(spe, oracle, prec):
     assert max_abs(m_g[~wide], m_o[~wide]) <= TOL[prec] and max_abs(c_g[~wide], c_o[~wide]) <= TOL[prec]
     scale = max(1.0, float(np.abs(c_o[wide]).max()))     # ill-conditioned by construction: relative to the covariance's size
     assert max_abs(m_g[wide], m_o[wide]) <= 10 * TOL[prec] and max_abs(c_g[wide], c_o[wide]) <= 10 * TOL[prec] * scale
+
+
+def _aniso(R, seed):
+    """Process noise whose rotated 3x3 diagonal blocks are full SPD matrices (the rotation of PoseUKF.cpp:184-185 /
+    OrientationUKF.cpp:84-85 matters), the rest as given."""
+    rng = np.random.default_rng(seed)
+    R = np.array(R, dtype=np.float64)
+    for b in (0, 3):
+        g = rng.uniform(-1, 1, (3, 3))
+        s = max(R[b, b], 1e-6)
+        R[b:b + 3, b:b + 3] = s * (np.diag([1.0, 0.3, 2.5]) + 0.4 * g @ g.T)
+    return R
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_rotated_process_noise_and_the_isotropic_shortcut(spe, oracle, prec):
+    """Batch-uniform noise with isotropic rotated blocks (the reference default, PoseUKF.cpp:104-107) lets the kernel skip the
+    rotation (R s I R^T = s I); anisotropic blocks must take the rotated path.  Both against the oracle, which always
+    rotates; Pose constant-velocity branch and OrientationState, fused and separate launches."""
+    n = N_SMALL
+    mu, cov = spe.synth.pose_initial(n)
+    for R in (spe.synth.pose_default_process_noise(), _aniso(spe.synth.pose_default_process_noise(), 3)):
+        eng = spe.BatchPoseUKF(n, precision=prec)
+        eng.initialize(mu, cov); eng.set_process_noise(R)
+        eng.predict(0.05)                                   # no acceleration latched: processModel + rotated noise * dt
+        m_g, c_g, _ = eng.state()
+        m_o, c_o, st = oracle.pose_predict(mu, cov, R, None, None, 0.05)
+        assert (eng.status() == 0).all() and (st == 0).all()
+        assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    s = spe.synth
+    mu, cov = s.orient_initial(n)
+    gyro, acc, z, Q = s.orient_cycle_inputs(n, 0, mu[:, :4])
+    for R in (s.orient_process_noise(), _aniso(s.orient_process_noise() * 1e3, 4)):
+        eng = spe.BatchOrientationUKF(n, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE, precision=prec)
+        eng.initialize(mu, cov); eng.set_process_noise(R); eng.set_orient_inputs(gyro, acc)
+        eng.cycle(0.02, spe.MEAS_ORIENT_BODYVEL3, z, Q)
+        m_g, c_g, _ = eng.state()
+        m_o, c_o, st = oracle.orient_predict(mu, cov, R, acc, gyro, s.ORIENT_TAU, s.ORIENT_TAU, eng.earth_rotation, 0.02)
+        m_o, c_o, st2 = oracle.orient_update(m_o, c_o, z, Q)
+        assert (eng.status() == 0).all() and (st == 0).all() and (st2 == 0).all()
+        assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    # a quaternion that is not of unit length switches the shortcut off for its wavefront (R R^T != I): still the oracle's result
+    mu, cov = spe.synth.pose_initial(8)
+    mu[2, 3:7] *= 1.01
+    eng = spe.BatchPoseUKF(8, precision=prec)
+    eng.initialize(mu, cov)
+    eng.predict(0.05)
+    m_g, c_g, _ = eng.state()
+    m_o, c_o, st = oracle.pose_predict(mu, cov, spe.synth.pose_default_process_noise(), None, None, 0.05)
+    assert (eng.status() == st).all()
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]

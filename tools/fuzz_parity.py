@@ -36,6 +36,15 @@ def spd3(rng, n, lo=1e-4, hi=0.3):
     return s * (np.eye(3) + 0.3 * g @ np.transpose(g, (0, 2, 1)))
 
 
+def aniso(rng, R):
+    """full SPD 3x3 blocks where the models rotate the noise (the isotropic default lets the kernel skip the rotation)"""
+    R = np.array(R, dtype=np.float64)
+    for b in (0, 3):
+        g = rng.uniform(-1, 1, (3, 3))
+        R[b:b + 3, b:b + 3] = max(R[b, b], 1e-9) * (np.diag(rng.uniform(0.2, 3.0, 3)) + 0.4 * g @ g.T)
+    return R
+
+
 def compare(tag, prec, m_g, c_g, st_g, m_o, c_o, st_o, fails, ctx):
     ok_state = st_o == st_g
     scale = max(1.0, float(np.nanmax(np.abs(c_o))) if c_o.size else 1.0)
@@ -62,6 +71,8 @@ def pose_scenario(rng, k, fails):
     mu[:, 10:13] *= 10.0 ** rng.uniform(-1, 1.5, (n, 1))                   # spin up to ~6 rad/s
     ctx = f"pose k={k} n={n} prec={'f64' if prec == 0 else 'f32'}"
     R = spe.synth.pose_default_process_noise() * 10.0 ** rng.uniform(-2, 1)
+    if rng.uniform() < 0.5:
+        R = aniso(rng, R)
     acc_cov = np.eye(3) * 10.0 ** rng.uniform(-4, -1)
     eng = spe.BatchPoseUKF(n, precision=prec)
     fused = spe.BatchPoseUKF(n, precision=prec)
@@ -128,6 +139,8 @@ def orient_scenario(rng, k, fails):
         cov[i, 0:3, :] *= np.sqrt(rot[i]); cov[i, :, 0:3] *= np.sqrt(rot[i])
     ctx = f"orient k={k} n={n} prec={'f64' if prec == 0 else 'f32'}"
     R = s.orient_process_noise() * 10.0 ** rng.uniform(-1, 2)
+    if rng.uniform() < 0.5:
+        R = aniso(rng, R)
     tau_g, tau_a = float(10.0 ** rng.uniform(1, 4)), float(10.0 ** rng.uniform(1, 4))
     eng = spe.BatchOrientationUKF(n, tau_g, tau_a, s.ORIENT_LATITUDE, precision=prec)
     eng.initialize(mu, cov); eng.set_process_noise(R)

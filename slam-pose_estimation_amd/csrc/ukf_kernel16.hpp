@@ -936,6 +936,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                     // the nonlinear 6x6 block are rotated.  Its 21 entries are evaluated ONCE per filter, at most two
                     // per lane, and parked in LDS; the tiles pick them up after the accumulation loop.  (Evaluating the
                     // rotation for every entry of every tile cost ~200 instructions per wavefront in the Orient cycle.)
+                    if (NZ_EARLY || !noise_plain)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const bool v = l + G * t < NL * (NL + 1) / 2;
@@ -999,23 +1000,35 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 // (weight 0: its neighbour's accumulators are finite sums of the same filter)
                 const T wsum = is_cross ? T(0) : T(1);
                 const bool writer = p_commit && (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
+                // (OrientationState with isotropic noise blocks: every entry is the plain table value that is already in
+                // flight, the shaped-noise table is neither filled nor read -- a second copy of the loop under a wave-uniform
+                // branch, because a branch per entry makes the register allocator spill)
+                auto store_tiles = [&](auto plain_c) {
+                    constexpr bool PLAIN = decltype(plain_c)::value;
 #pragma unroll
-                for (int i2 = 0; i2 < TR; ++i2)
+                    for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                    for (int j2 = 0; j2 < TC; ++j2) {
-                        const int r = R0 + i2, c = C0 + j2;
-                        const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
-                        const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                        T nv = nz[i2][j2];
-                        if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
-                            const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
-                            T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
-                            keep(shaped);
-                            nv = is_cross ? pl[i2][j2] : shaped;
+                        for (int j2 = 0; j2 < TC; ++j2) {
+                            const int r = R0 + i2, c = C0 + j2;
+                            const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
+                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
+                            T nv = nz[i2][j2];
+                            if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
+                                if constexpr (PLAIN) {
+                                    nv = pl[i2][j2];
+                                } else {
+                                    const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
+                                    T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
+                                    keep(shaped);
+                                    nv = is_cross ? pl[i2][j2] : shaped;
+                                }
+                            }
+                            const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
+                            PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
                         }
-                        const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
-                        PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
-                    }
+                };
+                if (!NZ_EARLY && noise_plain) store_tiles(std::true_type{});
+                else store_tiles(std::false_type{});
                 // affine block in place: the old entries are still staged
 #pragma unroll
                 for (int t = 0; t < AEL; ++t) {

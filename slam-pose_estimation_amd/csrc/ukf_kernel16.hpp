@@ -72,6 +72,25 @@ template <int C> UKFB_DEV void fmac_bcast(float& acc, float src, float m) {
 template <int C> UKFB_DEV void fmac_bcast(double& acc, double src, double m) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(C));
 }
+// 1 / (lane C's v): in fp32 the reciprocal reads its operand through DPP, no broadcast move.
+template <int C> UKFB_DEV float rcp_bcast(float v) {
+    float r;
+    asm volatile("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(C));
+    return r;
+}
+// (fp64: the assembler accepts v_rcp_f64_dpp, the hardware does not broadcast for it -- every pivot came out wrong; the move stays)
+template <int C> UKFB_DEV double rcp_bcast(double v) { return fast_rcp(row_bcast<C>(v)); }
+// true on every lane of a 16-lane row iff v holds on all 16 of them: one compare, the reduction is scalar (and-fold of the ballot
+// inside each 16-bit field, widened back to a lane mask); needs all 64 lanes active
+UKFB_DEV bool row_all(bool v) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+    unsigned long long t = b & (b >> 8);
+    t &= t >> 4;
+    t &= t >> 2;
+    t &= t >> 1;
+    t &= 0x0001000100010001ull;
+    return __builtin_amdgcn_inverse_ballot_w64((t << 16) - t);
+}
 UKFB_DEV void dpp_hazard_fence(float src) { asm volatile("s_nop 1" ::"v"(src)); }
 UKFB_DEV void dpp_hazard_fence(double src) { asm volatile("s_nop 1" ::"v"(src)); }
 // compile-time loop (DPP controls are immediates)
@@ -297,11 +316,13 @@ template <class T, int D, int LS, int KS = D, int PUB = KS> UKFB_DEV T chol16(T 
     const int lw = (l < D) ? l : (D - 1);
     static_for<0, KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const T akk = row_bcast<k>(a[k]);
-        good = good && (akk > T(0));
-        const T nt = -(a[k] * fast_rcp(akk));   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
+        dpp_hazard_fence(a[k]);   // written by the previous step's fused FMA, read through DPP from here on
+        if constexpr (k >= PUB) {   // not published: checked as it comes (the published pivots are checked once, below)
+            const T akk = row_bcast<k>(a[k]);
+            good = good && (akk > T(0));
+        }
+        const T nt = -(a[k] * rcp_bcast<k>(a[k]));   // trailing update needs 1/pivot only; 1/sqrt is taken once, at the end
         if constexpr (k + 1 < KS) {
-            dpp_hazard_fence(a[k]);
             static_for<k + 1, KS>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 fmac_bcast<c>(a[c], a[k], nt);   // a[c] -= t * A[c][k], lane c holds A[c][k]
@@ -311,10 +332,13 @@ template <class T, int D, int LS, int KS = D, int PUB = KS> UKFB_DEV T chol16(T 
     // rows above the pivot publish an exact zero, so consumers can read whole columns unmasked
 #pragma unroll
     for (int k = 0; k < PUB; ++k) Lc[k * LS + lw] = (l >= k) ? a[k] : T(0);
-    ok = good;
     wsync();
     const int lc = (l < PUB) ? l : (PUB - 1);
-    return fast_rsqrt(Lc[lc * LS + lc]);   // this lane's column scale 1/sqrt(pivot_l) (lanes >= PUB: the last published one)
+    const T pv = Lc[lc * LS + lc];
+    // pivot k is final once step k - 1 has run and is what column k publishes on its diagonal: lane l < PUB checks its own,
+    // one compare for all of them instead of one broadcast + compare per step
+    ok = good && row_all((l >= PUB) || (pv > T(0)));
+    return fast_rsqrt(pv);   // this lane's column scale 1/sqrt(pivot_l) (lanes >= PUB: the last published one)
 }
 
 // Row l of a packed lower-triangular matrix for chol16: one base address and immediate offsets, no selects.  The

@@ -210,6 +210,9 @@ template <class T> struct MT<OrientM<T>> {
     }
 };
 
+#ifndef UKFB_F32_TRIM
+#define UKFB_F32_TRIM 1   // 0: the fp32 Pose slice as before round 2's last trim (424 floats, 21 workgroups per CU): -2.7 %
+#endif
 template <class T, class M> struct Layout16 {
     static constexpr int VEC = 16 / int(sizeof(T));
     static constexpr int D = M::D, S = M::S, N = 2 * D + 1, PK = D * (D + 1) / 2;
@@ -236,14 +239,17 @@ template <class T, class M> struct Layout16 {
     static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor.  Where !LAF_ROW_D its zero row D
                                                             // (read by the cross lanes in their last trip) is not stored: it aliases the
                                                             // mean staging behind it - finite values that meet the table's exact-zero row
-    static constexpr bool LAF_ROW_D = !(M::MODEL == 0 && sizeof(T) == 8);   // only the fp64 Pose slice needs the trim
+    static constexpr bool LAF_ROW_D = !(M::MODEL == 0 && (sizeof(T) == 8 || UKFB_F32_TRIM));   // only the Pose slices need the trim
+    // fp32 Pose: the small regions packed to 8-byte instead of 16-byte boundaries bring the slice to 400 floats = 6400 B =
+    // 5 allocation granules: 24 workgroups per CU = 6 wavefronts per SIMD (77 VGPRs allow it)
+    static constexpr int alm(int x) { return (M::MODEL == 0 && sizeof(T) == 4 && UKFB_F32_TRIM) ? (x + 1) / 2 * 2 : al(x); }
     static constexpr int MISC = LAF + al((D + (LAF_ROW_D ? 1 : 0)) * ST);
     static constexpr int MUS = MISC;                        // S  : mean staging
-    static constexpr int ROT = MUS + al(S);                 // 9  : rotation matrix of the mean
-    static constexpr int ZQ = ROT + al(9);                  // 12 : z (3) + Q (9)
+    static constexpr int ROT = MUS + alm(S);                // 9  : rotation matrix of the mean
+    static constexpr int ZQ = ROT + alm(9);                 // 12 : z (3) + Q (9)
     static constexpr int NSH = ZQ + 12;                     // 21 : shaped process noise of the nonlinear block
-    static constexpr int DUM = NSH + al(21);                // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
-    static constexpr int PF_RAW = DUM + al(S);
+    static constexpr int DUM = NSH + alm(21);               // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
+    static constexpr int PF_RAW = DUM + alm(S);
     // Workgroups per CU follow the LDS allocation granule of 1280 B (measured, tools/lds_granule.hip; the occupancy API
     // assumes 512 B): the fp64 Pose slice must stay <= 12800 B per workgroup for 12 workgroups = 3 wavefronts per SIMD
     // (it was 13120 B = 11 workgroups per CU until round 2).
@@ -251,7 +257,7 @@ template <class T, class M> struct Layout16 {
     // a multiple of 32 dwords costs 25-50 %: every broadcast read becomes a 4-way conflict)
     static constexpr int PF = PF_RAW + (((PF_RAW * int(sizeof(T)) / 4) % 32 == 0) ? 2 * VEC : 0);
     static_assert(TNL + N * ST >= D * LS && D - NL <= ST && NL <= ST, "prediction tables");
-    static_assert(PF % VEC == 0 && LS >= D && LS <= 16 && S <= 16 && D + 1 <= 16, "scratch layout");
+    static_assert(PF % 2 == 0 && LS >= D && LS <= 16 && S <= 16 && D + 1 <= 16, "scratch layout");
 };
 
 template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layout16<T, M>::PF * int(sizeof(T)); }

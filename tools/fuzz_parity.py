@@ -174,6 +174,8 @@ def orient_scenario(rng, k, fails):
         if not compare(f"round {rnd} update", prec, m_g, c_g, st_g, m_o2, c_o2, st_o2, fails, ctx):
             return
         m_o, c_o = m_g.copy(), c_g.copy()
+        qc = m_f[:, 0:4] * np.array([-1.0, -1.0, -1.0, 1.0])          # the fused engine follows its own trajectory
+        z = np.stack([oracle.quat_rotate(qc[i], m_f[i, 4:7]) for i in range(n)]) + rng.normal(0, 0.03, (n, 3))
         fused.set_orient_inputs(gyro, acc)
         fused.cycle(dt, spe.MEAS_ORIENT_BODYVEL3, z, Q)
         m_g, c_g, _ = fused.state(); st_g = fused.status()

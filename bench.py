@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra-regions", action="store_true", help="skip the sustained / burst kernel timings")
+    ap.add_argument("--clock-warmup-seconds", type=float, default=0.4,
+                    help="untimed launches before the W warm-up steps (state restored afterwards) so that the GPU clocks have settled")
     ap.add_argument("--workload", choices=["pose", "pose-mixed", "orient"], default="pose",
                     help="pose: the headline metric (default). pose-mixed: BASELINE config 5 (per-filter model id over "
                          "the 9 Pose models, 25 %% inactive). orient: config 4 (OrientationState predict + body-velocity update)")
@@ -252,7 +254,7 @@ def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):
             m_o, c_o, _ = capi.pose_update(m_o, c_o, models, f32(z), f32(Q), threads=threads)
     em, ec = float(np.abs(m_g - m_o).max()), float(np.abs(c_g - c_o).max())
     tol = TOL[args.precision]
-    what = (f"after {cycles} fused cycles of this run (pre-roll + warm-up + timed)" if start is None else
+    what = (f"after {cycles} fused cycles of this run (warm-up + timed; the clock pre-roll is undone)" if start is None else
             f"cycles {k0}..{cycles - 1} of this run, from the GPU state downloaded before them")
     return {"max_abs_mu": em, "max_abs_cov": ec, "tol": tol, "ok": bool(em <= tol and ec <= tol),
             "sample": f"filters {first}..{first + sample - 1} {what}, GPU state vs oracle/ukf_oracle.hpp (fp64) replay "
@@ -406,12 +408,29 @@ def run_rank(args):
             step()
         return eng.timer_end() / k
 
-    # Untimed pre-roll: the FIRST burst of queued launches in a process is reported complete ~50 ms late by the
-    # runtime in about one process out of three (GPU timestamps show the kernels back to back; later bursts
-    # never, tools/sync_latency.py and DESIGN.md section 5).  A short burst (up to 64 launches)
-    # absorbs that one-time event before the W warm-up steps and the K timed steps.
-    for _ in range(min(args.steps, 64)):
-        step()
+    # Untimed pre-roll with the state put back afterwards.  (1) The FIRST burst of queued launches in a process is reported
+    # complete ~50 ms late by the runtime in about one process out of three (GPU timestamps show the kernels back to back; later
+    # bursts never, tools/sync_latency.py and DESIGN.md section 5).  (2) The clocks of an idle GPU need a few hundred
+    # milliseconds of work to settle: a 20-step region started 30 ms after the first launch measured 1.25 ms per launch on a box
+    # whose sustained figure was 1.15 ms.  So: bursts of 64 launches for --clock-warmup-seconds (default 0.4 s), then the
+    # initial state is restored, and the W warm-up and K timed steps run over the same cycles of the (non-stationary) workload
+    # as without the pre-roll.
+    mu_ptr, cov_ptr, _ = eng.device_views()
+    ts_ = "<f8" if prec == spe.F64 else "<f4"
+    mu_view = torch.as_tensor(_DevArray(mu_ptr, (per, S), ts_), device=dev)
+    cov_view = torch.as_tensor(_DevArray(cov_ptr, (per, eng.PK), ts_), device=dev)
+    if args.clock_warmup_seconds > 0:
+        init_state = (mu_view.clone(), cov_view.clone())
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.clock_warmup_seconds:
+            for _ in range(64):
+                step()
+            eng.sync()
+        mu_view.copy_(init_state[0]); cov_view.copy_(init_state[1])
+        torch.cuda.synchronize()
+        del init_state
+        done[0] = 0
     fence()
     for _ in range(args.warmup):
         step()
@@ -419,10 +438,6 @@ def run_rank(args):
     # snapshot of the warmed-up state (device to device) so that the extra kernel-time regions below start where
     # the timed region started: the headline workload is not stationary (the unobserved orientation covariance
     # grows with every cycle and moves the SO(3) maps onto their wide-angle paths)
-    mu_ptr, cov_ptr, _ = eng.device_views()
-    ts_ = "<f8" if prec == spe.F64 else "<f4"
-    mu_view = torch.as_tensor(_DevArray(mu_ptr, (per, S), ts_), device=dev)
-    cov_view = torch.as_tensor(_DevArray(cov_ptr, (per, eng.PK), ts_), device=dev)
     snap = None
     if not args.no_extra_regions:
         snap = (mu_view.clone(), cov_view.clone(), done[0])

@@ -263,6 +263,79 @@ template <class T, class M> struct Layout16 {
 template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layout16<T, M>::PF * int(sizeof(T)); }
 
 // ---------------------------------------------------------------------------------------------
+// Lane constants of the prediction's covariance phase.  Which tile a lane owns, where its operands sit in the LDS
+// slice and where its results go depends on the lane index alone -- not on the filter, not on the launch -- yet every
+// wavefront used to re-derive it (nibble decodes, triangular indices, predicates, address selects: ~80 of the ~130
+// non-FMA VALU instructions of the phase).  The values are tabulated at compile time instead: one row of byte offsets
+// per lane, fetched with two / four vector loads from constant memory.
+//   rd[l]  operands: row pointer, column pointer (LDS bytes from the slice base), the weight of the neighbour's half sum
+//          (bit pattern of T(1) for the two lanes that share a tile of the nonlinear block, T(0) for a cross lane),
+//          byte offsets of the lane's plain-noise entries (tile origin, affine entries)
+//   wr[l]  results: LDS byte offset of every tile entry and affine entry this lane stores (entries it does not own --
+//          beyond the diagonal, outside the matrix, the second half lane of a shared tile -- point at the store sink),
+//          then the offsets the affine entries are read from.  Row 16 = every store to the sink: the row of a lane
+//          whose filter does not commit its prediction, so that the stores need no predicate of their own.
+// ---------------------------------------------------------------------------------------------
+template <class T, class M> struct CovTab {
+    using LY = Layout16<T, M>;
+    static constexpr int D = M::D, NL = LY::NL, ST = LY::ST, TRIP = LY::TRIP, TR = MT<M>::TR, TC = MT<M>::TC;
+    static constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + 15) / 16;
+    static constexpr int NRD = 8, NWR = 16, SZ = int(sizeof(T));
+    static constexpr int RD_PR = 0, RD_PC = 1, RD_WS = 2, RD_NZ = 4, RD_ANZ = 5;   // rd row (RD_WS: one or two dwords)
+    static constexpr int WR_TILE = 0, WR_AFF = TR * TC, WR_AFF_RD = TR * TC + AEL;  // wr row
+    static_assert(RD_ANZ + AEL <= NRD && WR_AFF_RD + AEL <= NWR, "covariance lane tables");
+    struct Tabs {
+        uint32_t rd[16][NRD];
+        uint32_t wr[17][NWR];
+    };
+    static constexpr int tri_r(int e) {
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        return r;
+    }
+    static constexpr Tabs make() {
+        Tabs t{};
+        const uint32_t sink = uint32_t(LY::DUM * SZ);
+        for (int l = 0; l < 16; ++l) {
+            const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
+            const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
+            const bool is_cross = R0 >= NL;
+            const int half = is_cross ? 0 : (lw & 1);
+            t.rd[l][RD_PR] = uint32_t((is_cross ? (LY::LAF + (R0 - NL)) : (LY::TNL + half * (TRIP * ST) + R0)) * SZ);
+            t.rd[l][RD_PC] = uint32_t((LY::TNL + ((is_cross || half) ? (TRIP * ST) : 0) + C0) * SZ);
+            if (SZ == 8) {
+                t.rd[l][RD_WS] = 0u;
+                t.rd[l][RD_WS + 1] = is_cross ? 0u : 0x3FF00000u;
+            } else {
+                t.rd[l][RD_WS] = is_cross ? 0u : 0x3F800000u;
+            }
+            const int rc0 = R0 < D ? R0 : D - 1, cc0 = C0 < D ? C0 : D - 1;
+            t.rd[l][RD_NZ] = uint32_t((rc0 * D + cc0) * SZ);
+            const bool writer = (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
+            for (int i2 = 0; i2 < TR; ++i2)
+                for (int j2 = 0; j2 < TC; ++j2) {
+                    const int r = R0 + i2, c = C0 + j2;
+                    const bool w = writer && r < D && c <= r;
+                    t.wr[l][WR_TILE + i2 * TC + j2] = w ? uint32_t((LY::PKS + r * (r + 1) / 2 + c) * SZ) : sink;
+                }
+            for (int k = 0; k < AEL; ++k) {
+                const int e = l + 16 * k;
+                const bool v = e < NAB;
+                const int rr = v ? tri_r(e) : 0, cc = v ? (e - rr * (rr + 1) / 2) : 0;
+                const int ar = NL + rr, ac = NL + cc;
+                t.rd[l][RD_ANZ + k] = uint32_t((ar * D + ac) * SZ);
+                t.wr[l][WR_AFF + k] = v ? uint32_t((LY::PKS + ar * (ar + 1) / 2 + ac) * SZ) : sink;
+                t.wr[l][WR_AFF_RD + k] = uint32_t((LY::PKS + ar * (ar + 1) / 2 + ac) * SZ);
+            }
+        }
+        for (int k = 0; k < NWR; ++k) t.wr[16][k] = sink;
+        for (int k = 0; k < AEL; ++k) t.wr[16][WR_AFF_RD + k] = uint32_t((LY::PKS + NL * (NL + 1) / 2 + NL) * SZ);
+        return t;
+    }
+    static constexpr Tabs tabs = make();
+};
+
+// ---------------------------------------------------------------------------------------------
 // Cholesky: lane l < D holds row l (entries 0..l) in a[].  The factorisation itself runs on DPP row
 // broadcasts (lane c's A[c][k] for the trailing update, lane k's pivot); column k is published UNSCALED
 // (v_l = a_l[k], pivot included) with one LDS write for the consumers.  L[c][k] = Lc[k*LS+c]*rs_k
@@ -504,6 +577,11 @@ constexpr unsigned long long tri_cols(int first) {
 // minimum waves per SIMD for the register allocator (LDS admits 3 in fp64, 6 in fp32)
 // fp64 first mean iteration: 1 = transpose the NL sums through LDS, 0 = quad sums + broadcast FMAs in registers
 // (same-box A/B: 908 vs 902 M filter-cycles/s for Pose, 582 vs 585 for Orient -- a wash; the transposition stays)
+// scheduling fence between the process models of the + and - sigma point (1: the two run one after the other; 0: the
+// scheduler may interleave the two independent chains)
+#ifndef UKFB_SF_PROC
+#define UKFB_SF_PROC 1
+#endif
 #ifndef UKFB_MEAN1_TRANSPOSE
 #define UKFB_MEAN1_TRANSPOSE 1
 #endif
@@ -729,7 +807,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             const bool pc = do_p && ok;            // this filter's predict will be committed
             sfence();
             process_fast((M*)nullptr, xp, pin);    // lanes >= D carry the centre point (their column is zero)
-            sfence();
+            if constexpr (UKFB_SF_PROC != 0) sfence();
             process_fast((M*)nullptr, xm, pin);
             sfence();
             UKFB_MARK("p_mean1");
@@ -880,6 +958,13 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 }
             }
             UKFB_MARK("p_delta_r");
+            // lane constants of the covariance phase (CovTab, Pose kernels), requested here so that they have arrived when it starts
+            uint32_t ctr[CovTab<T, M>::NRD];
+            if constexpr (M::MODEL == 0) {
+                const uint32_t* rrow = CovTab<T, M>::tabs.rd[l];
+#pragma unroll
+                for (int k = 0; k < CovTab<T, M>::NRD; ++k) ctr[k] = rrow[k];
+            }
             {   // rotation deltas to the final mean; quaternion of the mean.  The loop's last trip took the logarithms
                 // against the reference BEFORE its (sub-tolerance) move al: re-base them to first order in al, exact in
                 // the delta (remainder < 4e-14 under the bounds tested here); anything else takes the logarithms again.
@@ -916,158 +1001,268 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
             // each plus the shaped process noise.  Lane -> one TR x TC tile (MT<M>::TILE_R / TILE_C): a tile of the
             // nonlinear block is shared by two lanes (rows 0..D and D+1..N of the table, N = zero row), a tile of the
             // cross block belongs to one lane (rows 0..D of A and W, D = zero row): TRIP = D + 1 iterations for all.
-            const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
-            const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
-            const bool is_cross = R0 >= NL;
-            const int half = is_cross ? 0 : (lw & 1);
-            const T* pr = is_cross ? (LAF + (R0 - NL)) : (TAB + half * (TRIP * ST) + R0);
-            const T* pc_ = TAB + ((is_cross || half) ? (TRIP * ST) : 0) + C0;   // cross: the W rows
-            // shaped process noise of this lane's tile: with a plain table (Pose acceleration branch) it is
-            // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
-            // (it would hold 2 x TR x TC products in flight across the loop)
-            constexpr bool NZ_EARLY = (M::MODEL == 0);
-            constexpr bool TILES_INSIDE = (M::MODEL == 0);   // Pose: every tile entry is a valid (row, column); Orient: rows 13, 14 are not
-            static_assert(!TILES_INSIDE || (10 + TR <= D && 3 + TC <= NL), "Pose tile table");
-            constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
-            const T* Rn = a.Rn + fc * a.Rn_stride;
-            const T* Ra = a.Racc + fc * a.Rn_stride;
-            const bool all_acc = NZ_EARLY && UKFB_HEADLINE_ACC(wave_all(pin.use_acc));
-            // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
-            // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
-            int ar[AEL], ac[AEL];
-            bool av[AEL];
+            // Which tile a lane owns, where its operands and results live is a function of the lane index alone.  The Pose
+            // kernels read it from CovTab (byte offsets, one row per lane) instead of decoding it in every wavefront:
+            // -60 VALU instructions per wavefront, +1.5 % on the fp32 engine, which is issue-bound (same-box A/B; the
+            // latency-bound fp64 engine +0.4 %).  The OrientationState kernels keep the decoded form: their 3 x 3 tiles need
+            // twice the table loads, and with them config 4 measured -1.4 %.
+            constexpr bool LANE_TABLES = (M::MODEL == 0);
+            if constexpr (LANE_TABLES) {
+                using CT = CovTab<T, M>;
+                static_assert(10 + TR <= D && 3 + TC <= NL, "Pose tile table: every tile entry is a valid (row, column)");
+                constexpr int AEL = CT::AEL;   // affine block entries per lane
+                unsigned char* const wbase = reinterpret_cast<unsigned char*>(base);
+                const T* pr = reinterpret_cast<const T*>(wbase + ctr[CT::RD_PR]);
+                const T* pc_ = reinterpret_cast<const T*>(wbase + ctr[CT::RD_PC]);   // cross: the W rows
+                // results: the row of the lane, or the all-sink row when this filter's prediction is not committed
+                uint32_t ctw[CT::NWR];
+                {
+                    const uint32_t* wrow = CT::tabs.wr[pc ? l : 16];
 #pragma unroll
-            for (int t = 0; t < AEL; ++t) {
-                av[t] = l + G * t < NAB;
-                ar[t] = NL + int((tri_rows(G * t) >> (4 * l)) & 15ull);
-                ac[t] = NL + int((tri_cols(G * t) >> (4 * l)) & 15ull);
-            }
-            T acc[TR][TC], nz[TR][TC], anz[AEL];
-            {
+                    for (int k = 0; k < CT::WR_AFF_RD + AEL; ++k) ctw[k] = wrow[k];
+                }
+                const T* Rn = a.Rn + fc * a.Rn_stride;
+                const T* Ra = a.Racc + fc * a.Rn_stride;
+                // element imm behind byte offset off of the table p
+                const auto at_off = [](const T* p, uint32_t off, int imm) {
+                    return reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p) + off)[imm];
+                };
+                // plain (un-rotated) noise entry (cf. plain_noise_entry16)
+                const auto plain_off = [&](uint32_t off, int imm) {
+                    const T rn = at_off(Rn, off, imm), vacc = at_off(Ra, off, imm);
+                    return pin.use_acc ? vacc : pin.dt * rn;
+                };
+                const bool all_acc = UKFB_HEADLINE_ACC(wave_all(pin.use_acc));
+                // shaped process noise of this lane's tile: requested before the accumulation loop, consumed after it
+                T acc[TR][TC], nz[TR][TC], anz[AEL];
 #pragma unroll
                 for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                     for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = nz[i2][j2] = T(0);
 #pragma unroll
                 for (int t = 0; t < AEL; ++t) anz[t] = T(0);
-                if (all_acc) {   // wave-uniform: plain table reads, all in flight together
+                if (all_acc) {   // wave-uniform: plain table reads (acceleration branch: raw noise), all in flight together
 #pragma unroll
                     for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                        for (int j2 = 0; j2 < TC; ++j2) {
-                            const int r = R0 + i2, c = C0 + j2;
-                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                            nz[i2][j2] = Ra[rc * D + cc];
-                        }
+                        for (int j2 = 0; j2 < TC; ++j2) nz[i2][j2] = at_off(Ra, ctr[CT::RD_NZ], i2 * D + j2);
 #pragma unroll
-                    for (int t = 0; t < AEL; ++t) anz[t] = Ra[ar[t] * D + ac[t]];
+                    for (int t = 0; t < AEL; ++t) anz[t] = at_off(Ra, ctr[CT::RD_ANZ + t], 0);
                 } else {
-                    // Rotated noise (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85): only the two 3x3 diagonal blocks of
-                    // the nonlinear 6x6 block are rotated.  Its 21 entries are evaluated ONCE per filter, at most two
-                    // per lane, and parked in LDS; the tiles pick them up after the accumulation loop.  (Evaluating the
-                    // rotation for every entry of every tile cost ~200 instructions per wavefront in the Orient cycle.)
-                    if (NZ_EARLY || !noise_plain)
+                    // Rotated noise (PoseUKF.cpp:184-185): only the two 3x3 diagonal blocks of the nonlinear 6x6 block are
+                    // rotated.  Its 21 entries are evaluated ONCE per filter, at most two per lane, and parked in LDS.
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const bool v = l + G * t < NL * (NL + 1) / 2;
                         const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
-                        // (isotropic blocks, noise_plain: the table entry itself, no rotation and no rotation matrix)
-                        const T ne = (M::MODEL != 0 && noise_plain) ? plain_noise_entry16<T, M>(Rn, Ra, pin, r, c)
-                                                                    : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
-                        NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = ne;
+                        NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
                     }
-                    if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
+                    const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
+                    const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
+                    const bool is_cross = R0 >= NL;
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) {
+                            const int rn_ = is_cross ? 0 : (R0 + i2), cn_ = is_cross ? 0 : (C0 + j2);   // a nonlinear tile: rows / columns < NL
+                            T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
+                            keep(shaped);
+                            const T plain = plain_off(ctr[CT::RD_NZ], i2 * D + j2);
+                            nz[i2][j2] = is_cross ? plain : shaped;
+                        }
+#pragma unroll
+                    for (int t = 0; t < AEL; ++t) anz[t] = plain_off(ctr[CT::RD_ANZ + t], 0);
+                }
+#pragma unroll
+                for (int i = 0; i < TRIP; ++i) {
+                    T vr[TR], vc[TC];
+#pragma unroll
+                    for (int k = 0; k < TR; ++k) vr[k] = pr[i * ST + k];
+#pragma unroll
+                    for (int k = 0; k < TC; ++k) vc[k] = pc_[i * ST + k];
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = fma(vr[i2], vc[j2], acc[i2][j2]);
+                }
+                p_commit = pc;
+                st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
+                st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
+                // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
+                // (weight 0: its neighbour's accumulators are finite sums of the same filter)
+                T wsum;
+                if constexpr (sizeof(T) == 8)
+                    wsum = __builtin_bit_cast(T, (unsigned long long)ctr[CT::RD_WS] | ((unsigned long long)ctr[CT::RD_WS + 1] << 32));
+                else
+                    wsum = __builtin_bit_cast(T, ctr[CT::RD_WS]);
+#pragma unroll
+                for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < TC; ++j2) {
+                        const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
+                        *reinterpret_cast<T*>(wbase + ctw[CT::WR_TILE + i2 * TC + j2]) = tot + nz[i2][j2];
+                    }
+                // affine block in place (unit scale): the old entries are still staged
+#pragma unroll
+                for (int t = 0; t < AEL; ++t) {
+                    T old = *reinterpret_cast<const T*>(wbase + ctw[CT::WR_AFF_RD + t]);
+                    keep(old);
+                    *reinterpret_cast<T*>(wbase + ctw[CT::WR_AFF + t]) = old + anz[t];
+                }
+            } else {
+                const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
+                const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
+                const bool is_cross = R0 >= NL;
+                const int half = is_cross ? 0 : (lw & 1);
+                const T* pr = is_cross ? (LAF + (R0 - NL)) : (TAB + half * (TRIP * ST) + R0);
+                const T* pc_ = TAB + ((is_cross || half) ? (TRIP * ST) : 0) + C0;   // cross: the W rows
+                // shaped process noise of this lane's tile: with a plain table (Pose acceleration branch) it is
+                // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
+                // (it would hold 2 x TR x TC products in flight across the loop)
+                constexpr bool NZ_EARLY = (M::MODEL == 0);
+                constexpr bool TILES_INSIDE = (M::MODEL == 0);   // Pose: every tile entry is a valid (row, column); Orient: rows 13, 14 are not
+                static_assert(!TILES_INSIDE || (10 + TR <= D && 3 + TC <= NL), "Pose tile table");
+                constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
+                const T* Rn = a.Rn + fc * a.Rn_stride;
+                const T* Ra = a.Racc + fc * a.Rn_stride;
+                const bool all_acc = NZ_EARLY && UKFB_HEADLINE_ACC(wave_all(pin.use_acc));
+                // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
+                // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
+                int ar[AEL], ac[AEL];
+                bool av[AEL];
+#pragma unroll
+                for (int t = 0; t < AEL; ++t) {
+                    av[t] = l + G * t < NAB;
+                    ar[t] = NL + int((tri_rows(G * t) >> (4 * l)) & 15ull);
+                    ac[t] = NL + int((tri_cols(G * t) >> (4 * l)) & 15ull);
+                }
+                T acc[TR][TC], nz[TR][TC], anz[AEL];
+                {
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = nz[i2][j2] = T(0);
+#pragma unroll
+                    for (int t = 0; t < AEL; ++t) anz[t] = T(0);
+                    if (all_acc) {   // wave-uniform: plain table reads, all in flight together
 #pragma unroll
                         for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                             for (int j2 = 0; j2 < TC; ++j2) {
                                 const int r = R0 + i2, c = C0 + j2;
-                                const int rn_ = is_cross ? 0 : r, cn_ = is_cross ? 0 : c;   // a nonlinear tile: rows / columns < NL
-                                T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
-                                keep(shaped);
-                                const T plain = plain_noise_entry16<T, M>(Rn, Ra, pin, r, c);
-                                nz[i2][j2] = is_cross ? plain : shaped;
+                                const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
+                                nz[i2][j2] = Ra[rc * D + cc];
                             }
 #pragma unroll
-                        for (int t = 0; t < AEL; ++t) anz[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
-                    }
-                }
-            }
+                        for (int t = 0; t < AEL; ++t) anz[t] = Ra[ar[t] * D + ac[t]];
+                    } else {
+                        // Rotated noise (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85): only the two 3x3 diagonal blocks of
+                        // the nonlinear 6x6 block are rotated.  Its 21 entries are evaluated ONCE per filter, at most two
+                        // per lane, and parked in LDS; the tiles pick them up after the accumulation loop.  (Evaluating the
+                        // rotation for every entry of every tile cost ~200 instructions per wavefront in the Orient cycle.)
+                        if (NZ_EARLY || !noise_plain)
 #pragma unroll
-            for (int i = 0; i < TRIP; ++i) {
-                T vr[TR], vc[TC];
-#pragma unroll
-                for (int k = 0; k < TR; ++k) vr[k] = pr[i * ST + k];
-#pragma unroll
-                for (int k = 0; k < TC; ++k) vc[k] = pc_[i * ST + k];
-#pragma unroll
-                for (int i2 = 0; i2 < TR; ++i2)
-#pragma unroll
-                    for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = fma(vr[i2], vc[j2], acc[i2][j2]);
-            }
-            p_commit = pc;
-            st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
-            st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
-            {
-                // Orient picks its noise up late: ALL global loads of this lane's entries are issued here, together,
-                // before anything waits for one of them (issued one by one between the stores below they cost a full
-                // L2 round trip each: eleven in a row were 20 % of the Orient wavefront's life)
-                T pl[TR][TC], apl[AEL];
-                if constexpr (!NZ_EARLY) {
-#pragma unroll
-                    for (int i2 = 0; i2 < TR; ++i2)
-#pragma unroll
-                        for (int j2 = 0; j2 < TC; ++j2) {
-                            const int r = R0 + i2, c = C0 + j2;
-                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                            pl[i2][j2] = plain_noise_entry16<T, M>(Rn, Ra, pin, rc, cc);
+                        for (int t = 0; t < 2; ++t) {
+                            const bool v = l + G * t < NL * (NL + 1) / 2;
+                            const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
+                            // (isotropic blocks, noise_plain: the table entry itself, no rotation and no rotation matrix)
+                            const T ne = (M::MODEL != 0 && noise_plain) ? plain_noise_entry16<T, M>(Rn, Ra, pin, r, c)
+                                                                        : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                            NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = ne;
                         }
+                        if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
 #pragma unroll
-                    for (int t = 0; t < AEL; ++t) apl[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
-                    sfence();
-                }
-                // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
-                // (weight 0: its neighbour's accumulators are finite sums of the same filter)
-                const T wsum = is_cross ? T(0) : T(1);
-                const bool writer = p_commit && (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
-                // (OrientationState with isotropic noise blocks: every entry is the plain table value that is already in
-                // flight, the shaped-noise table is neither filled nor read -- a second copy of the loop under a wave-uniform
-                // branch, because a branch per entry makes the register allocator spill)
-                auto store_tiles = [&](auto plain_c) {
-                    constexpr bool PLAIN = decltype(plain_c)::value;
+                            for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                    for (int i2 = 0; i2 < TR; ++i2)
-#pragma unroll
-                        for (int j2 = 0; j2 < TC; ++j2) {
-                            const int r = R0 + i2, c = C0 + j2;
-                            const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
-                            const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                            T nv = nz[i2][j2];
-                            if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
-                                if constexpr (PLAIN) {
-                                    nv = pl[i2][j2];
-                                } else {
-                                    const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
+                                for (int j2 = 0; j2 < TC; ++j2) {
+                                    const int r = R0 + i2, c = C0 + j2;
+                                    const int rn_ = is_cross ? 0 : r, cn_ = is_cross ? 0 : c;   // a nonlinear tile: rows / columns < NL
                                     T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
                                     keep(shaped);
-                                    nv = is_cross ? pl[i2][j2] : shaped;
+                                    const T plain = plain_noise_entry16<T, M>(Rn, Ra, pin, r, c);
+                                    nz[i2][j2] = is_cross ? plain : shaped;
                                 }
-                            }
-                            const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
-                            PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
-                        }
-                };
-                if (!NZ_EARLY && noise_plain) store_tiles(std::true_type{});
-                else store_tiles(std::false_type{});
-                // affine block in place: the old entries are still staged
 #pragma unroll
-                for (int t = 0; t < AEL; ++t) {
-                    const int idx = ar[t] * (ar[t] + 1) / 2 + ac[t];
-                    T old = PKS[idx];
-                    keep(old);
-                    const T nv = NZ_EARLY ? anz[t] : apl[t];
-                    const T ss = (M::MODEL == 0) ? T(1) : MT<M>::aff_scale(ar[t], pin) * MT<M>::aff_scale(ac[t], pin);
-                    PKS[(p_commit && av[t]) ? idx : (LY::DUM - LY::PKS)] = fma(ss, old, nv);
+                            for (int t = 0; t < AEL; ++t) anz[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TRIP; ++i) {
+                    T vr[TR], vc[TC];
+#pragma unroll
+                    for (int k = 0; k < TR; ++k) vr[k] = pr[i * ST + k];
+#pragma unroll
+                    for (int k = 0; k < TC; ++k) vc[k] = pc_[i * ST + k];
+#pragma unroll
+                    for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = fma(vr[i2], vc[j2], acc[i2][j2]);
+                }
+                p_commit = pc;
+                st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
+                st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
+                {
+                    // Orient picks its noise up late: ALL global loads of this lane's entries are issued here, together,
+                    // before anything waits for one of them (issued one by one between the stores below they cost a full
+                    // L2 round trip each: eleven in a row were 20 % of the Orient wavefront's life)
+                    T pl[TR][TC], apl[AEL];
+                    if constexpr (!NZ_EARLY) {
+#pragma unroll
+                        for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                            for (int j2 = 0; j2 < TC; ++j2) {
+                                const int r = R0 + i2, c = C0 + j2;
+                                const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
+                                pl[i2][j2] = plain_noise_entry16<T, M>(Rn, Ra, pin, rc, cc);
+                            }
+#pragma unroll
+                        for (int t = 0; t < AEL; ++t) apl[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
+                        sfence();
+                    }
+                    // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
+                    // (weight 0: its neighbour's accumulators are finite sums of the same filter)
+                    const T wsum = is_cross ? T(0) : T(1);
+                    const bool writer = p_commit && (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
+                    // (OrientationState with isotropic noise blocks: every entry is the plain table value that is already in
+                    // flight, the shaped-noise table is neither filled nor read -- a second copy of the loop under a wave-uniform
+                    // branch, because a branch per entry makes the register allocator spill)
+                    auto store_tiles = [&](auto plain_c) {
+                        constexpr bool PLAIN = decltype(plain_c)::value;
+#pragma unroll
+                        for (int i2 = 0; i2 < TR; ++i2)
+#pragma unroll
+                            for (int j2 = 0; j2 < TC; ++j2) {
+                                const int r = R0 + i2, c = C0 + j2;
+                                const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
+                                const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
+                                T nv = nz[i2][j2];
+                                if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
+                                    if constexpr (PLAIN) {
+                                        nv = pl[i2][j2];
+                                    } else {
+                                        const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
+                                        T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
+                                        keep(shaped);
+                                        nv = is_cross ? pl[i2][j2] : shaped;
+                                    }
+                                }
+                                const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
+                                PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
+                            }
+                    };
+                    if (!NZ_EARLY && noise_plain) store_tiles(std::true_type{});
+                    else store_tiles(std::false_type{});
+                    // affine block in place: the old entries are still staged
+#pragma unroll
+                    for (int t = 0; t < AEL; ++t) {
+                        const int idx = ar[t] * (ar[t] + 1) / 2 + ac[t];
+                        T old = PKS[idx];
+                        keep(old);
+                        const T nv = NZ_EARLY ? anz[t] : apl[t];
+                        const T ss = (M::MODEL == 0) ? T(1) : MT<M>::aff_scale(ar[t], pin) * MT<M>::aff_scale(ac[t], pin);
+                        PKS[(p_commit && av[t]) ? idx : (LY::DUM - LY::PKS)] = fma(ss, old, nv);
+                    }
                 }
             }
             UKFB_MARK("p_end");

@@ -199,6 +199,21 @@ int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const
 int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
                    const void* Q_dev);
 
+/* `cycles` consecutive fused cycles in ONE launch (replay of buffered samples, catching up after a stall, fixed-rate
+ * sensors whose samples are batched): predictionStep(dt) + integrateMeasurement(meas_model) `cycles` times for every
+ * filter, exactly as `cycles` calls of ukfb_cycle_dev would -- same arithmetic, bit-identical state -- but the filter
+ * stays in LDS between its cycles: the state crosses HBM once per launch instead of once per cycle.
+ * The samples sit in rings of `slots` input sets on the device, engine precision: z_dev [slots][capacity][3],
+ * Q_dev [slots][capacity][9]; cycle c (0-based) reads slot (first_slot + c) % slots.  in_a_dev / in_b_dev
+ * ([slots][capacity][3], either may be NULL) replace the latched inputs per cycle in the same way -- Pose: in_a =
+ * acceleration (acc.mu of integrateMeasurement(AccelerationMeasurement), PoseUKF.cpp:175-178; NaN = no acceleration,
+ * constant-velocity branch), in_b unused; Orient: in_a = acceleration.mu, in_b = rotation_rate.mu
+ * (OrientationUKF.cpp:53-63); NULL: the inputs latched in the engine serve every cycle.  The latches themselves are
+ * not modified.  After the call the status word of a filter is the OR over its cycles; a cycle whose prediction is
+ * gated or fails is skipped for that filter as in a single launch, the following cycles still run. */
+int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, int slots, int first_slot,
+                         const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev);
+
 /* fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]) per filter, one launch.
  * ts_us[i] < 0: filter i has no sample in this call (untouched, status INACTIVE);
  * model[i] < 0: prediction only.  Host arrays [capacity] / device arrays in engine precision. */

@@ -926,6 +926,53 @@ int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int3
     return launch(e, r);
 }
 
+int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, int slots, int first_slot,
+                         const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev) {
+    if (!e || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    if (cycles < 0 || slots < 1 || first_slot < 0 || first_slot >= slots)
+        return fail(UKFB_ERR_INVALID_ARG, "cycles >= 0, slots >= 1, 0 <= first_slot < slots");
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    if (cycles == 0) return UKFB_OK;
+    if (e->cfg.lanes_per_filter != 16) {
+        // the one-wavefront-per-filter layouts have no multi-cycle kernel: one launch per cycle, same results.  The
+        // status word must still be the OR over the cycles.
+        const size_t w = e->tsize;
+        const void* keep_a = e->in_a_bound;
+        const void* keep_b = e->in_b_bound;
+        int rc = UKFB_OK;
+        for (int c = 0; c < cycles && rc == UKFB_OK; ++c) {
+            const size_t s = size_t((first_slot + c) % slots) * size_t(e->cap);
+            if (in_a_dev) e->in_a_bound = static_cast<const char*>(in_a_dev) + s * 3 * w;
+            if (in_b_dev) e->in_b_bound = static_cast<const char*>(in_b_dev) + s * 3 * w;
+            ukfb::LaunchReq r;
+            r.do_predict = true;
+            r.do_update = true;
+            r.dt_uniform = dt;
+            r.meas_uniform = meas_model;
+            r.z_dev = static_cast<const char*>(z_dev) + s * 3 * w;
+            r.Q_dev = static_cast<const char*>(Q_dev) + s * 9 * w;
+            r.status_accumulate = c > 0;
+            rc = launch(e, r);
+        }
+        e->in_a_bound = keep_a;
+        e->in_b_bound = keep_b;
+        return rc;
+    }
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.do_update = true;
+    r.dt_uniform = dt;
+    r.meas_uniform = meas_model;
+    r.z_dev = z_dev;
+    r.Q_dev = Q_dev;
+    r.cycles = cycles;
+    r.slots = slots;
+    r.first_slot = first_slot;
+    r.in_a_slots = in_a_dev;
+    r.in_b_slots = in_b_dev;
+    return launch(e, r);
+}
+
 int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q) {
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");

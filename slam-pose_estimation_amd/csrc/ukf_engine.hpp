@@ -82,6 +82,10 @@ struct LaunchReq {
     const int32_t* filter_index_dev = nullptr;
     int64_t n_items = -1;
     bool status_accumulate = false;
+    // multi-cycle launch (ukfb_cycle_multi_dev): cycles > 0 selects it; in_a_slots / in_b_slots replace the latched inputs
+    int cycles = 0, first_slot = 0, slots = 1;
+    const void* in_a_slots = nullptr;
+    const void* in_b_slots = nullptr;
 };
 
 int launch_pose_f64(ukfb_engine* e, const LaunchReq& r);

@@ -73,6 +73,12 @@ template <class T> struct KArgs {
     T mean_tol;
     int mean_max_it;
     T gate_chi2;                 // < 0: accept any
+    // ---- multi-cycle launches (tuned kernel, fused cycle only): cyc_count consecutive cycles in one launch, the filter
+    // state stays in LDS between them.  Cycle c reads input slot (cyc_first + c) % cyc_ring of z, Q ([cyc_ring][cyc_items]
+    // [3], [..][9]) and of in_a (cyc_in & 1) / in_b (cyc_in & 2) when they are slotted ([cyc_ring][cyc_items][3]); otherwise
+    // the latched inputs serve every cycle.  Single-cycle launches leave all of this zero.
+    int cyc_count, cyc_first, cyc_ring, cyc_in;
+    int64_t cyc_items;
 #ifdef UKFB_STAMPS
     unsigned long long* stamps;  // diagnostic build: [grid][UKFB_MAX_STAMPS] s_memtime per phase marker
 #endif

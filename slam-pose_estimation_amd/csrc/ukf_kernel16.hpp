@@ -593,8 +593,12 @@ constexpr unsigned long long tri_cols(int first) {
 #endif
 template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W64 : UKFB_W32; }
 
-template <class T, class M, bool DO_PREDICT, bool DO_UPDATE>
-__global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
+// MULTI (fused cycle only): KArgs::cyc_count consecutive cycles in one launch.  The filter is staged in LDS once, every
+// cycle reads its own input slot (requested one cycle ahead), the state goes back to HBM after the last cycle; the status
+// word is the OR over the cycles.  MULTI = false compiles the single-cycle kernel exactly as before (trip count 1).
+template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false>
+__global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
+    static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
     constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
@@ -612,12 +616,19 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
 #else
 #define UKFB_HEADLINE_ACC(x) (x)
 #endif
+    if constexpr (MULTI) {
+        // multi-cycle launches are direct launches with one dt and one measurement model for every filter (checked by the
+        // host): no per-filter timestamps, time steps, model ids, activity flags or filter index list to keep alive
+        __builtin_assume(a.fidx == nullptr); __builtin_assume(a.ts == nullptr); __builtin_assume(a.dt == nullptr);
+        __builtin_assume(a.meas == nullptr); __builtin_assume(a.active == nullptr);
+    }
     const int lane = threadIdx.x;
-    const int g = lane >> 4, l = lane & 15;
-    const int64_t f = int64_t(blockIdx.x) * FPW + g;
-    const bool fvalid = f < a.n;
-    const int64_t fi = fvalid ? f : (a.n - 1);                    // work item: index of the per-call inputs
-    const int64_t fc = a.fidx ? int64_t(a.fidx[fi]) : fi;         // filter: index of the engine's state
+    // (not const: a multi-cycle launch re-derives everything that follows from the lane index in every cycle, see below)
+    int g = lane >> 4, l = lane & 15;
+    int64_t f = int64_t(blockIdx.x) * FPW + g;
+    bool fvalid = f < a.n;
+    int64_t fi = fvalid ? f : (a.n - 1);                    // work item: index of the per-call inputs
+    int64_t fc = a.fidx ? int64_t(a.fidx[fi]) : fi;         // filter: index of the engine's state
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC;
     T* TAB = base + LY::TNL;
@@ -628,8 +639,10 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     T* ZQ = base + LY::ZQ;
     T* NSH = base + LY::NSH;
     T* DUMP = base + LY::DUM;
-    const bool has_pair = l < D;       // lane owns the sigma pair of column l
-    const bool has_ctr = l == D;       // lane owns the centre point
+    bool has_pair = l < D;       // lane owns the sigma pair of column l
+    bool has_ctr = l == D;       // lane owns the centre point
+    double dt_uniform_c = a.dt_uniform;   // launch-wide time step and measurement model (scalars)
+    int meas_uniform_c = a.meas_uniform;
 
     UKFB_MARK("prologue");
     // ---- prologue: EVERY per-filter stream is requested before the first dependent instruction, so the kernel
@@ -661,19 +674,42 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     }
     const T mu_l = a.mu[fc * S + ((l < S) ? l : (S - 1))];
     ProcIn<T> pin;
-    if constexpr (DO_PREDICT) {
-        const T* pa = a.in_a + fc * 3;   // latched inputs: the engine always passes both arrays (its own or the bound ones)
-        const T* pb = a.in_b + fc * 3;
+    // per-call inputs of one input slot (single-cycle launches: slot 0 = the arrays themselves)
+    const auto load_inputs = [&](int slot, T (&ia)[3], T (&ib)[3], T& zq) {
+        const int64_t so = MULTI ? int64_t(slot) * a.cyc_items : 0;
+        if constexpr (DO_PREDICT) {
+            // latched inputs: the engine always passes both arrays (its own or the bound ones)
+            const T* pa = a.in_a + ((MULTI && (a.cyc_in & 1)) ? so + fc : fc) * 3;
+            const T* pb = a.in_b + ((MULTI && (a.cyc_in & 2)) ? so + fc : fc) * 3;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            pin.a[k] = pa[k];
-            pin.w[k] = pb[k];
+            for (int k = 0; k < 3; ++k) {
+                ia[k] = pa[k];
+                ib[k] = pb[k];
+            }
         }
-    }
+        if constexpr (DO_UPDATE) {
+            const T* zp = (l < 3) ? (a.z + (so + fi) * 3 + l) : (a.Q + (so + fi) * 9 + ((l < 12) ? (l - 3) : 0));
+            zq = *zp;
+        }
+    };
     T zq_l = T(0);
-    if constexpr (DO_UPDATE) {
-        const T* zp = (l < 3) ? (a.z + fi * 3 + l) : (a.Q + fi * 9 + ((l < 12) ? (l - 3) : 0));
-        zq_l = *zp;
+    int slot = MULTI ? a.cyc_first : 0;
+    if constexpr (MULTI) {
+        load_inputs(slot, pin.a, pin.w, zq_l);
+    } else {
+        if constexpr (DO_PREDICT) {
+            const T* pa = a.in_a + fc * 3;
+            const T* pb = a.in_b + fc * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pin.a[k] = pa[k];
+                pin.w[k] = pb[k];
+            }
+        }
+        if constexpr (DO_UPDATE) {
+            const T* zp = (l < 3) ? (a.z + fi * 3 + l) : (a.Q + fi * 9 + ((l < 12) ? (l - 3) : 0));
+            zq_l = *zp;
+        }
     }
 
     UKFB_MARK("stage");
@@ -684,10 +720,61 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = cov_l[t];
     }
     MUS[(l < S) ? l : (LY::DUM - LY::MUS)] = mu_l;
+    const bool live = fvalid && (init_b != 0);
+    uint32_t st_all = ST_OK;   // OR over the cycles of the launch
+    bool changed = false;      // some cycle committed: the state goes back to HBM
+    const int ncyc = MULTI ? a.cyc_count : 1;
+    // ---- cycles of this launch (one, unless MULTI).  The body is not indented: it is the single-cycle kernel.
+    int cyc = 0;
+    do {   // (a do-while: with MULTI = false its condition is a constant and no loop exists at all)
+    if constexpr (MULTI) {
+        // Everything derived from the lane index is loop-invariant, and the compiler would hoist all of it -- addresses,
+        // predicates, decoded tables: a hundred registers held across the whole cycle, spills in every MULTI kernel.  The
+        // lane index is therefore passed through an opaque move in every cycle and its derivatives are formed again.
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        g = lane_c >> 4;
+        l = lane_c & 15;
+        f = int64_t(blockIdx.x) * FPW + g;
+        fvalid = f < a.n;
+        fi = fvalid ? f : (a.n - 1);
+        fc = fi;   // (multi-cycle launches are direct: no filter index list)
+        base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
+        Lc = base + LY::LC;
+        TAB = base + LY::TNL;
+        PKS = base + LY::PKS;
+        LAF = base + LY::LAF;
+        MUS = base + LY::MUS;
+        ROT = base + LY::ROT;
+        ZQ = base + LY::ZQ;
+        NSH = base + LY::NSH;
+        DUMP = base + LY::DUM;
+        has_pair = l < D;
+        has_ctr = l == D;
+        // the same for the two launch-wide scalars whose derivatives (time gate, selection tables of the measurement
+        // model) are evaluated with vector instructions: opaque scalar moves
+        dt_uniform_c = a.dt_uniform;
+        meas_uniform_c = a.meas_uniform;
+        asm volatile("" : "+s"(dt_uniform_c));
+        asm volatile("" : "+s"(meas_uniform_c));
+    }
+    // fp64 (3 wavefronts per SIMD, latency-bound): the inputs of the next cycle are requested before this cycle's
+    // arithmetic, into registers.  fp32 (6 per SIMD, issue-bound, 3 registers from its budget): every cycle loads its own.
+    constexpr bool PREFETCH = MULTI && sizeof(T) == 8;
+    T nx_a[3] = {T(0), T(0), T(0)}, nx_w[3] = {T(0), T(0), T(0)}, nx_zq = T(0);
+    if constexpr (MULTI) {
+        if constexpr (PREFETCH) {   // (the last cycle re-reads its own slot)
+            const int nslot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
+            slot = (cyc + 1 < ncyc) ? nslot : slot;
+            load_inputs(slot, nx_a, nx_w, nx_zq);
+        } else if (cyc > 0) {
+            slot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
+            load_inputs(slot, pin.a, pin.w, zq_l);
+        }
+    }
     if constexpr (DO_UPDATE) ZQ[(l < 12) ? l : (LY::DUM - LY::ZQ)] = zq_l;
 
     uint32_t st = ST_OK;
-    const bool live = fvalid && (init_b != 0);
     st |= (fvalid && !live) ? ST_UNINITIALISED : 0u;
 
     UKFB_MARK("gate");
@@ -702,14 +789,14 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         double dt;
         if (!use_ts && !a.dt) {
             // one dt for the whole launch (kernel argument): the gate is scalar arithmetic, one select per lane
-            dt = a.dt_uniform;
+            dt = dt_uniform_c;
             const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
             const uint32_t code = neg ? ST_ERR_NEG_DT : (small ? ST_SKIPPED_SMALL_DT : (large ? ST_ERR_DT_TOO_LARGE : 0u));
             st |= live ? code : 0u;
             p_error = live && (neg || (!small && large));
             do_p = live && code == 0u;
         } else {
-            dt = a.dt ? dt_l : a.dt_uniform;
+            dt = a.dt ? dt_l : dt_uniform_c;
             if (use_ts)   // the IEEE division of base::Time::toSeconds only where it is needed
                 dt = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
             ts_store = use_ts && live && l == 0 && !noev && (first || dt > a.min_dt);
@@ -735,7 +822,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
     bool do_u = false;
     int mid = -1;
     if constexpr (DO_UPDATE) {
-        mid = a.meas ? mid_l : a.meas_uniform;
+        mid = a.meas ? mid_l : meas_uniform_c;
         const bool act = M::meas_valid(mid) && (a.active ? act_b != 0 : true);
         do_u = live && act && !p_error && !noev;
         st |= (live && !do_u) ? ST_INACTIVE : 0u;
@@ -1302,7 +1389,7 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
                 // One model id for the whole launch (a kernel argument, i.e. scalar) that selects a full 3-vector --
                 // position, velocity or angular velocity: three consecutive tangent components from a scalar base,
                 // so every index below is scalar arithmetic and nothing needs a select.
-                const int mu_id = a.meas_uniform;
+                const int mu_id = meas_uniform_c;
                 const bool uni3 = (a.meas == nullptr) && (mu_id == 0 || mu_id == 4 || mu_id == 8);
                 if (uni3) {
                     const int tb = (mu_id == 0) ? 0 : ((mu_id == 4) ? 6 : 9);   // first tangent index
@@ -1678,9 +1765,21 @@ __global__ void __launch_bounds__(64, min_waves16<T>()) ukf_kernel16(const KArgs
         }
     }
 
+    changed = changed || p_commit || u_commit;
+    st_all |= st;
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pin.a[k] = nx_a[k];
+            pin.w[k] = nx_w[k];
+        }
+        zq_l = nx_zq;
+    }
+    } while (MULTI && ++cyc < ncyc);   // cycles
+
     UKFB_MARK("commit");
     // =========================================================================== commit
-    const bool changed = p_commit || u_commit;
+    const uint32_t st = st_all;
     if (changed && fvalid) {
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {

@@ -53,7 +53,9 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
     (void)hipMemsetAsync(dbuf, 0, need * 8, e->stream);
     args.stamps = dbuf;
     const dim3 gd((unsigned)grid), bd(64);
-    if (r.do_predict && r.do_update)
+    if (r.cycles > 0)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, e->stream, args);
+    else if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
     else if (r.do_predict)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, e->stream, args);
@@ -95,7 +97,8 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     constexpr int FPW = 4;
     const int64_t grid = (args.n + FPW - 1) / FPW;
     const int lds = FPW * lds_bytes_per_filter16<T, M>();
-    const char* mode = r.do_predict ? (r.do_update ? "cycle" : "predict") : "update";
+    const bool multi = r.cycles > 0;   // ukfb_cycle_multi_dev: fused cycles only (checked by the caller)
+    const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? "cycle" : "predict") : "update");
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
                      (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
     e->last_lds = lds;
@@ -106,7 +109,9 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
 #ifdef UKFB_STAMPS
     return launch_row16_stamped<T, M>(e, r, args, grid, lds);
 #endif
-    if (r.do_predict && r.do_update)
+    if (multi)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, e->stream, args);
+    else if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
     else if (r.do_predict)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, e->stream, args);
@@ -153,6 +158,15 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
     a.mean_tol = T(e->cfg.mean_tol);
     a.mean_max_it = e->cfg.mean_max_iter;
     a.gate_chi2 = T(e->cfg.gate_chi2);
+    if (r.cycles > 0) {
+        a.cyc_count = r.cycles;
+        a.cyc_first = r.first_slot;
+        a.cyc_ring = r.slots;
+        a.cyc_items = e->cap;
+        a.cyc_in = (r.in_a_slots ? 1 : 0) | (r.in_b_slots ? 2 : 0);
+        if (r.in_a_slots) a.in_a = static_cast<const T*>(r.in_a_slots);
+        if (r.in_b_slots) a.in_b = static_cast<const T*>(r.in_b_slots);
+    }
     switch (e->cfg.lanes_per_filter) {
         case 64: return launch_g<T, M, 64>(e, r, a);
         case 32: return launch_g<T, M, 32>(e, r, a);

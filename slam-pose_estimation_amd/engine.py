@@ -42,7 +42,8 @@ EXPORTS = [
     "ukfb_pose_set_acceleration", "ukfb_pose_bind_acceleration_dev", "ukfb_orient_set_params",
     "ukfb_orient_set_inputs", "ukfb_orient_bind_inputs_dev", "ukfb_orient_get_rotation_rate", "ukfb_predict",
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
-    "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_last_launch_info",
+    "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_cycle_multi_dev",
+    "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
     "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
 ]
@@ -294,6 +295,15 @@ class BatchUKF:
     def cycle_dev(self, dt: float, meas_model_uniform: int, z_dev, Q_dev, meas_model_dev=None):
         _chk(self._lib.ukfb_cycle_dev(self._h, C.c_double(dt), C.c_int(meas_model_uniform), _devptr(meas_model_dev),
                                       _devptr(z_dev), _devptr(Q_dev)), "ukfb_cycle_dev")
+
+    def cycle_multi_dev(self, cycles: int, dt: float, meas_model: int, z_dev, Q_dev, slots: int, first_slot: int = 0,
+                        in_a_dev=None, in_b_dev=None):
+        """`cycles` fused cycles in one launch, the filters stay in LDS in between; cycle c reads slot (first_slot + c) % slots
+        of the device rings z_dev [slots][capacity][3], Q_dev [slots][capacity][9] and, if given, in_a_dev / in_b_dev
+        [slots][capacity][3] (Pose: acceleration; Orient: acceleration, rotation rate) in place of the latched inputs."""
+        _chk(self._lib.ukfb_cycle_multi_dev(self._h, C.c_int(cycles), C.c_double(dt), C.c_int(meas_model), C.c_int(slots),
+                                            C.c_int(first_slot), _devptr(in_a_dev), _devptr(in_b_dev), _devptr(z_dev),
+                                            _devptr(Q_dev)), "ukfb_cycle_multi_dev")
 
     def cycle_timestamps(self, ts_us, meas_model, z, Q):
         """Fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]); ts < 0: no sample."""

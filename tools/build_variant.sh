@@ -11,7 +11,7 @@ obj=$out/obj_$name
 mkdir -p $obj
 pids=""
 for tu in ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize "$@" \
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -disable-machine-licm "$@" \
       -Rpass-analysis=kernel-resource-usage -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.remarks &
   pids="$pids $!"
 done

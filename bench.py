@@ -46,6 +46,7 @@ N_RING = 4                         # input sets the steps cycle through
 SUSTAINED_STEPS = 500
 BURST_STEPS = 20
 RECENT_CYCLES = 16                 # window of the second in-run parity check
+MULTI_CYCLES = 8                   # cycles per launch of the extra multi-cycle region (ukfb_cycle_multi_dev)
 TOL = {"f64": 1e-9, "f32": 1e-4}   # north_star
 
 
@@ -77,6 +78,9 @@ def parse():
     ap.add_argument("--workload", choices=["pose", "pose-mixed", "orient"], default="pose",
                     help="pose: the headline metric (default). pose-mixed: BASELINE config 5 (per-filter model id over "
                          "the 9 Pose models, 25 %% inactive). orient: config 4 (OrientationState predict + body-velocity update)")
+    ap.add_argument("--cycles-per-launch", type=int, default=1,
+                    help="C > 1: the K timed cycles run as launches of C cycles each (ukfb_cycle_multi_dev: the filters stay "
+                         "in LDS between the cycles of a launch); a step is still one predict+update cycle")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of "
                     "the N>1 plumbing on a box with fewer GPUs than ranks)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -359,10 +363,15 @@ def run_rank(args):
         eng.set_process_noise(sy.orient_process_noise())
     else:
         eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
-    acc_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(N_RING)]
-    gyr_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(N_RING)] if orient else None
-    z_d = [torch.empty((per, 3), dtype=tdtype, device=dev) for _ in range(N_RING)]
-    Q_d = [torch.empty((per, 9), dtype=tdtype, device=dev) for _ in range(N_RING)]
+    # input rings [N_RING][filters][..], contiguous (a multi-cycle launch addresses its slots inside them); *_d: the slots
+    acc_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
+    gyr_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev) if orient else None
+    z_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
+    Q_ring = torch.empty((N_RING, per, 9), dtype=tdtype, device=dev)
+    acc_d = [acc_ring[k] for k in range(N_RING)]
+    gyr_d = [gyr_ring[k] for k in range(N_RING)] if orient else None
+    z_d = [z_ring[k] for k in range(N_RING)]
+    Q_d = [Q_ring[k] for k in range(N_RING)]
     m_d = [torch.empty((per,), dtype=torch.int32, device=dev) for _ in range(N_RING)] if args.workload == "pose-mixed" else None
     for lo in range(0, per, CH):
         hi = min(per, lo + CH)
@@ -391,6 +400,10 @@ def run_rank(args):
 
     done = [0]   # fused cycles applied to the engine so far (the parity replay needs the exact count)
 
+    cpl = [max(1, args.cycles_per_launch)]   # cycles per launch of run_cycles (the extra multi-cycle region changes it)
+    if cpl[0] > 1 and m_d is not None:
+        raise SystemExit("--cycles-per-launch > 1 needs one measurement model for the batch (not --workload pose-mixed)")
+
     def step():
         r = done[0] % N_RING
         if orient:
@@ -401,11 +414,29 @@ def run_rank(args):
             eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r], meas_model_dev=m_d[r] if m_d else None)
         done[0] += 1
 
+    def run_cycles(k):
+        """exactly k fused cycles: single launches, or launches of cpl cycles (the last one shorter); returns the launches"""
+        if cpl[0] == 1:
+            for _ in range(k):
+                step()
+            return k
+        launches = 0
+        while k > 0:
+            c = min(cpl[0], k)
+            if orient:
+                eng.cycle_multi_dev(c, DT, spe.MEAS_ORIENT_BODYVEL3, z_ring, Q_ring, N_RING, done[0] % N_RING,
+                                    in_a_dev=acc_ring, in_b_dev=gyr_ring)
+            else:
+                eng.cycle_multi_dev(c, DT, spe.MEAS_POS3, z_ring, Q_ring, N_RING, done[0] % N_RING, in_a_dev=acc_ring)
+            done[0] += c
+            k -= c
+            launches += 1
+        return launches
+
     def kernel_region(k):
-        """mean kernel time (ms) of k back-to-back launches: HIP events on the engine's stream"""
+        """mean kernel time (ms) per cycle of k back-to-back cycles: HIP events on the engine's stream"""
         eng.timer_begin()
-        for _ in range(k):
-            step()
+        run_cycles(k)
         return eng.timer_end() / k
 
     # Untimed pre-roll with the state put back afterwards.  (1) The FIRST burst of queued launches in a process is reported
@@ -424,16 +455,14 @@ def run_rank(args):
         torch.cuda.synchronize()
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.clock_warmup_seconds:
-            for _ in range(64):
-                step()
+            run_cycles(64)
             eng.sync()
         mu_view.copy_(init_state[0]); cov_view.copy_(init_state[1])
         torch.cuda.synchronize()
         del init_state
         done[0] = 0
     fence()
-    for _ in range(args.warmup):
-        step()
+    run_cycles(args.warmup)
     fence()
     # snapshot of the warmed-up state (device to device) so that the extra kernel-time regions below start where
     # the timed region started: the headline workload is not stationary (the unobserved orientation covariance
@@ -444,8 +473,7 @@ def run_rank(args):
         torch.cuda.synchronize()
     eng.timer_begin()           # HIP events on the stream the kernel is launched on
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    launches = run_cycles(args.steps)
     kernel_ms_total = eng.timer_end()
     fence()
     elapsed_local = time.perf_counter() - t0
@@ -464,8 +492,7 @@ def run_rank(args):
         parity = parity_check(args, spe, eng, first, sample, done[0], orient)
         m0, c0, _ = eng.state(0, sample)
         k0 = done[0]
-        for _ in range(RECENT_CYCLES):
-            step()
+        run_cycles(RECENT_CYCLES)
         eng.sync()
         parity_recent = parity_check(args, spe, eng, first, sample, done[0], orient, start=(m0, c0, k0))
 
@@ -484,8 +511,11 @@ def run_rank(args):
         del gathered
 
     # ---- kernel time under sustained clocks and in a burst (a 20-step timed region alone shows neither)
-    kernel_ms = kernel_ms_total / args.steps
+    kernel_ms = kernel_ms_total / args.steps          # per cycle (= per launch unless --cycles-per-launch > 1)
+    kernel_ms_launch = kernel_ms_total / launches
+    info = eng.last_launch_info()
     sustained_ms = burst_ms = None
+    multi = None
     if not args.no_extra_regions:
         def restore():
             eng.sync()
@@ -500,13 +530,29 @@ def run_rank(args):
         time.sleep(1.0)    # let the clocks recover
         burst_ms = kernel_region(BURST_STEPS)
         fence()
+        if cpl[0] == 1 and m_d is None and info["filters_per_workgroup"] == 4:
+            # the same cycles once more as launches of MULTI_CYCLES cycles (ukfb_cycle_multi_dev): the filters stay in LDS
+            # between the cycles of a launch.  Reported beside the headline, never as `value`.
+            restore()
+            cpl[0] = MULTI_CYCLES
+            k_multi = (max(args.steps, 64) + MULTI_CYCLES - 1) // MULTI_CYCLES * MULTI_CYCLES
+            run_cycles(MULTI_CYCLES)      # first launch of this kernel (code load), untimed
+            restore()
+            ms = kernel_region(k_multi)
+            eng.sync()
+            multi = {"cycles_per_launch": MULTI_CYCLES, "cycles": k_multi, "kernel_ms_per_cycle": ms,
+                     "filter_cycles_per_s_per_gpu": per / (ms * 1e-3), "kernel": eng.last_launch_info()["kernel"],
+                     "status_or": eng.status_summary(),
+                     "note": "same start state and input ring as the timed region; kernel time (HIP events) of this rank"}
+            cpl[0] = 1
+            fence()
 
-    info = eng.last_launch_info()
     if rank == 0:
         tsize = 8 if prec == spe.F64 else 4
         value = total * args.steps / elapsed
-        alg_bytes_launch = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * tsize * per
-        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        cycles_launch = args.steps / launches     # cycles of an average launch (1 unless --cycles-per-launch > 1)
+        alg_bytes_launch = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * tsize * per * cycles_launch
+        achieved = alg_bytes_launch / (kernel_ms_launch * 1e-3) / 1e9
         traffic_e, exact = load_profile_entry("traffic_latest.json", info["kernel"], per)
         traffic = None
         if traffic_e is not None:   # bytes per launch scale with the filters of the launch (per-filter streams only)
@@ -556,9 +602,11 @@ def run_rank(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": info["kernel"], "kernel_ms_per_launch": kernel_ms,
-                         "kernel_ms_per_launch_sustained": sustained_ms, "kernel_ms_per_launch_burst": burst_ms,
-                         "frac_sustained": (alg_bytes_launch / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sustained_ms else None,
+                         "kernel": info["kernel"], "kernel_ms_per_launch": kernel_ms_launch,
+                         "cycles_per_launch": cycles_launch,
+                         "kernel_ms_per_launch_sustained": sustained_ms * cycles_launch if sustained_ms else None,
+                         "kernel_ms_per_launch_burst": burst_ms * cycles_launch if burst_ms else None,
+                         "frac_sustained": (alg_bytes_launch / (sustained_ms * cycles_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if sustained_ms else None,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "lds_bytes_per_workgroup": info["lds_bytes"],
                          "valu": valu},
@@ -569,6 +617,7 @@ def run_rank(args):
             "gather_ms": gather_ms,
             "parity": parity,
             "parity_recent": parity_recent,
+            "multi_cycle": multi,
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "pose":
             out["cpu_baseline"] = cpu_baseline(args)

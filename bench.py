@@ -75,8 +75,10 @@ def parse():
     ap.add_argument("--no-extra-regions", action="store_true", help="skip the sustained / burst kernel timings")
     ap.add_argument("--clock-warmup-seconds", type=float, default=0.4,
                     help="untimed launches before the W warm-up steps (state restored afterwards) so that the GPU clocks have settled")
-    ap.add_argument("--workload", choices=["pose", "pose-mixed", "orient"], default="pose",
-                    help="pose: the headline metric (default). pose-mixed: BASELINE config 5 (per-filter model id over "
+    ap.add_argument("--workload", choices=["pose", "pose-cv", "pose-mixed", "orient"], default="pose",
+                    help="pose: the headline metric (default). pose-cv: the same without a latched acceleration -- the "
+                         "constant-velocity branch of predictionStepImpl (PoseUKF.cpp:195: rotated noise, scaled by dt), "
+                         "SURVEY 8(d)'s secondary run. pose-mixed: BASELINE config 5 (per-filter model id over "
                          "the 9 Pose models, 25 %% inactive). orient: config 4 (OrientationState predict + body-velocity update)")
     ap.add_argument("--cycles-per-launch", type=int, default=1,
                     help="C > 1: the K timed cycles run as launches of C cycles each (ukfb_cycle_multi_dev: the filters stay "
@@ -254,7 +256,8 @@ def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):
         m_o, c_o = (f32(mu), f32(cov)) if start is None else (start[0], start[1])
         for k in range(k0, cycles):
             acc, z, Q, models = ring[k % N_RING]
-            m_o, c_o, _ = capi.pose_predict(m_o, c_o, R, f32(acc), acc_cov, DT, threads=threads)
+            m_o, c_o, _ = capi.pose_predict(m_o, c_o, R, None if args.workload == "pose-cv" else f32(acc), acc_cov, DT,
+                                            threads=threads)
             m_o, c_o, _ = capi.pose_update(m_o, c_o, models, f32(z), f32(Q), threads=threads)
     em, ec = float(np.abs(m_g - m_o).max()), float(np.abs(c_g - c_o).max())
     tol = TOL[args.precision]
@@ -400,6 +403,7 @@ def run_rank(args):
 
     done = [0]   # fused cycles applied to the engine so far (the parity replay needs the exact count)
 
+    cv = args.workload == "pose-cv"   # no acceleration latched (the engine's default is NaN): constant-velocity branch
     cpl = [max(1, args.cycles_per_launch)]   # cycles per launch of run_cycles (the extra multi-cycle region changes it)
     if cpl[0] > 1 and m_d is not None:
         raise SystemExit("--cycles-per-launch > 1 needs one measurement model for the batch (not --workload pose-mixed)")
@@ -410,7 +414,8 @@ def run_rank(args):
             eng.bind_orient_inputs_dev(gyr_d[r], acc_d[r])
             eng.cycle_dev(DT, spe.MEAS_ORIENT_BODYVEL3, z_d[r], Q_d[r])
         else:
-            eng.bind_acceleration_dev(acc_d[r])
+            if not cv:
+                eng.bind_acceleration_dev(acc_d[r])
             eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r], meas_model_dev=m_d[r] if m_d else None)
         done[0] += 1
 
@@ -427,7 +432,8 @@ def run_rank(args):
                 eng.cycle_multi_dev(c, DT, spe.MEAS_ORIENT_BODYVEL3, z_ring, Q_ring, N_RING, done[0] % N_RING,
                                     in_a_dev=acc_ring, in_b_dev=gyr_ring)
             else:
-                eng.cycle_multi_dev(c, DT, spe.MEAS_POS3, z_ring, Q_ring, N_RING, done[0] % N_RING, in_a_dev=acc_ring)
+                eng.cycle_multi_dev(c, DT, spe.MEAS_POS3, z_ring, Q_ring, N_RING, done[0] % N_RING,
+                                    in_a_dev=None if cv else acc_ring)
             done[0] += c
             k -= c
             launches += 1
@@ -555,11 +561,14 @@ def run_rank(args):
         achieved = alg_bytes_launch / (kernel_ms_launch * 1e-3) / 1e9
         traffic_e, exact = load_profile_entry("traffic_latest.json", info["kernel"], per)
         traffic = None
-        if traffic_e is not None:   # bytes per launch scale with the filters of the launch (per-filter streams only)
+        # a multi-cycle entry holds per-launch counters of its own cycles per launch: only the same launch shape is comparable
+        same_shape = lambda e: e is not None and abs(float(e.get("cycles_per_launch", 1.0)) - cycles_launch) < 1e-9   # noqa: E731
+        if same_shape(traffic_e):   # bytes per launch scale with the filters of the launch (per-filter streams only)
             traffic = float(traffic_e["hbm_bytes_per_launch"]) * (1.0 if exact else per / float(traffic_e["filters_per_launch"]))
         pmc_e, _ = load_profile_entry("pmc_latest.json", info["kernel"], per)
         valu = None
-        if pmc_e is not None:
+        kernel_ms = kernel_ms_launch   # everything below is per launch
+        if same_shape(pmc_e):
             # VALU-issue roofline: wave-instructions per launch x issue cycles per instruction, against what the
             # SIMDs can issue during the kernel's measured duration at the clock the PMC pass observed
             # (GRBM_GUI_ACTIVE / 8 / kernel time, MI355X_MICROARCH.md "DVFS give-back")
@@ -593,7 +602,8 @@ def run_rank(args):
             "data": "synthetic",
             "config": {"workload": (f"{total} OrientationState UKF filters, fused predict(gyro+acc, dt=0.01)"
                                     f"+body-velocity update per step, {args.precision}, {per} filters per GPU" if orient else
-                                    f"{total} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)+"
+                                    f"{total} PoseWithVelocity UKF filters, fused predict("
+                                    + ("constant-velocity branch" if args.workload == "pose-cv" else "acc branch") + ", dt=0.01)+"
                                     + ("per-filter measurement model (9 models, 25 % inactive)" if args.workload == "pose-mixed"
                                        else "PositionMeasurement") + f" update per step, {args.precision}, {per} filters per GPU"),
                        "filters": total, "filters_per_gpu": per,

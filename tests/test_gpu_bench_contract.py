@@ -50,6 +50,9 @@ def test_bench_line_has_the_contract_fields():
     for key in ("parity", "parity_recent"):      # in-run parity against the oracle, fp64 tolerance of north_star
         p = d[key]
         assert p["tol"] == 1e-9 and p["ok"] is True and p["max_abs_mu"] <= 1e-9 and p["max_abs_cov"] <= 1e-9, p
+    m = d["multi_cycle"]                          # extra region: the same cycles as launches of 8 (never the headline value)
+    assert m["cycles_per_launch"] == 8 and m["cycles"] % 8 == 0 and m["kernel_ms_per_cycle"] > 0 and m["status_or"] == 0
+    assert "multicycle" in m["kernel"] and r["cycles_per_launch"] == 1 and "multicycle" not in r["kernel"]
 
 
 def test_bench_other_workloads_run():
@@ -58,7 +61,20 @@ def test_bench_other_workloads_run():
     assert d["dtype"] == "f32" and "OrientationState" in d["metric"] and d["status_or"] == 0
     assert d["parity_recent"]["ok"] is True and d["parity_recent"]["tol"] == 1e-4
     d = run_bench("--workload", "pose-mixed", "--filters", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
-    assert d["value"] > 0 and d["parity"]["ok"] is True
+    assert d["value"] > 0 and d["parity"]["ok"] is True and d["multi_cycle"] is None
+    # SURVEY 8(d)'s secondary run: the constant-velocity branch (no acceleration latched)
+    d = run_bench("--workload", "pose-cv", "--filters", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert "constant-velocity" in d["config"]["workload"] and d["status_or"] == 0 and d["parity"]["ok"] is True
+
+
+def test_bench_cycles_per_launch():
+    """K timed cycles as launches of C cycles (ukfb_cycle_multi_dev): exactly K cycles, parity against the oracle replay"""
+    d = run_bench("--filters", "8192", "--steps", "13", "--warmup", "3", "--cycles-per-launch", "4", "--no-cpu-baseline")
+    r = d["roofline"]
+    assert d["steps"] == 13 and "multicycle" in r["kernel"] and abs(r["cycles_per_launch"] - 13 / 4) < 1e-9
+    assert d["status_or"] == 0 and d["parity"]["ok"] is True and d["parity_recent"]["ok"] is True
+    assert "after 16 fused cycles" in d["parity"]["sample"]
+    assert abs(d["value"] - 8192 * 13 / (d["ms_per_step"] * 13e-3)) / d["value"] < 1e-6
 
 
 def test_single_rank_rccl_rehearsal():

@@ -34,6 +34,8 @@ cfg cfg2 --filters 65536
 cfg cfg3 --filters 131072 --precision f32
 cfg cfg4 --workload orient --precision f32 --filters 4194304
 cfg cfg5 --workload pose-mixed --filters 262144
+cfg multi8_f64 --cycles-per-launch 8 --warmup 16
+cfg multi8_f32 --cycles-per-launch 8 --warmup 16 --precision f32
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --filters 65536 > $out/trace_cfg2.json 2> $out/trace_cfg2.err
 # kernel stats of the default command (the driver's own invocation and the 500-step default)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions > $out/trace_default.json 2> $out/trace_default.err

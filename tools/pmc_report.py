@@ -44,7 +44,7 @@ for prec in ("f64", "f32"):
     calib[prec] = {"known_bytes": known, "FETCH_SIZE_bytes": fc, "WRITE_SIZE_bytes": wc, "k_read": known / fc, "k_write": known / wc}
 
 traffic, pmc, lines = [], [], []
-for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5"):
+for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "multi8_f64", "multi8_f32"):
     try:
         bench = json.loads(open(os.path.join(out, f"{name}_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     except Exception as e:
@@ -57,7 +57,8 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5"):
     write = mean_counter(f"{name}_WRITE_SIZE", "WRITE_SIZE", "ukf_kernel") * 1024.0
     c = calib[prec]
     hbm = fetch * c["k_read"] + write * c["k_write"]
-    traffic.append({"config": name, "kernel": kern, "filters_per_launch": n, "precision": prec, "calibration": c,
+    cpl = float(bench["roofline"].get("cycles_per_launch", 1.0))   # multi-cycle launches: counters are per launch of cpl cycles
+    traffic.append({"config": name, "kernel": kern, "filters_per_launch": n, "cycles_per_launch": cpl, "precision": prec, "calibration": c,
                     "raw": {"FETCH_SIZE_bytes": fetch, "WRITE_SIZE_bytes": write},
                     "hbm_read_bytes_per_launch": fetch * c["k_read"], "hbm_write_bytes_per_launch": write * c["k_write"],
                     "hbm_bytes_per_launch": hbm,
@@ -91,7 +92,7 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5"):
                     + 4.0 * cls["INT64"] + 4.0 * cls["CVT"] + 3.5 * other)
         cls["other(mov,select,compare,dpp mov)"] = other
         cls["dpp_fused_fp32_static"] = dpp_fused
-    e = {"config": name, "kernel": kern, "filters_per_launch": n, "precision": prec,
+    e = {"config": name, "kernel": kern, "filters_per_launch": n, "cycles_per_launch": cpl, "precision": prec,
          "valu_classes_per_wave": cls, "issue_cycles_per_wave_weighted": weighted,
          "valu_issue_frac_weighted_in_pass": (weighted * waves / (1024 * clock_mhz * 1e6 * ns * 1e-9)) if weighted else None,
          "valu_insts_per_wave": valu / waves, "lds_insts_per_wave": lds / waves,

@@ -52,6 +52,13 @@ public:
     void integrateMixedMeasurements(const int32_t* model, const double* z, const double* Q) { check(ukfb_update_mixed(engine, model, z, Q)); }
     /** fused predictionStep + integrateMeasurement in one launch */
     void cycle(double delta_t, int model, const double* z, const double* Q) { check(ukfb_cycle(engine, delta_t, model, z, Q)); }
+    /** `cycles` fused cycles in one launch, the filters stay on chip in between: buffered fixed-rate samples, one input set
+     *  per cycle (z [cycles][N][3], Q [cycles][N][9]; in_a / in_b [cycles][N][3] or NULL = the latched inputs).
+     *  Pose: in_a = acceleration; Orient: in_a = acceleration, in_b = rotation rate */
+    void cycles(int cycles, double delta_t, int model, const double* in_a, const double* in_b, const double* z, const double* Q)
+    {
+        check(ukfb_cycle_multi(engine, cycles, delta_t, model, in_a, in_b, z, Q));
+    }
     /** fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]); ts < 0: no sample, model < 0: predict only */
     void cycleFromSampleTimes(const int64_t* ts_us, const int32_t* model, const double* z, const double* Q) { check(ukfb_cycle_timestamps(engine, ts_us, model, z, Q)); }
     /** time-ordered asynchronous stream of samples in any arrival order (the batched stream aligner); returns the number of launches */

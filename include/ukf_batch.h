@@ -213,6 +213,10 @@ int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int3
  * gated or fails is skipped for that filter as in a single launch, the following cycles still run. */
 int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, int slots, int first_slot,
                          const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev);
+/* the same from host arrays of doubles, one input set per cycle: z [cycles][capacity][3], Q [cycles][capacity][3][3],
+ * in_a / in_b [cycles][capacity][3] or NULL (uploaded to an engine-owned ring, then one launch) */
+int ukfb_cycle_multi(ukfb_engine* e, int cycles, double dt, int meas_model, const double* in_a, const double* in_b,
+                     const double* z, const double* Q);
 
 /* fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]) per filter, one launch.
  * ts_us[i] < 0: filter i has no sample in this call (untouched, status INACTIVE);

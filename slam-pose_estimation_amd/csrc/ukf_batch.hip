@@ -507,7 +507,8 @@ int ukfb_destroy(ukfb_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->acc_cov_dev, e->in_a, e->in_b, e->z_stage,
-                    e->Q_stage, e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->cvt_dev};
+                    e->Q_stage, e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->cvt_dev,
+                    e->multi_dev};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -971,6 +972,38 @@ int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, 
     r.in_a_slots = in_a_dev;
     r.in_b_slots = in_b_dev;
     return launch(e, r);
+}
+
+int ukfb_cycle_multi(ukfb_engine* e, int cycles, double dt, int meas_model, const double* in_a, const double* in_b,
+                     const double* z, const double* Q) {
+    if (!e || !z || !Q) return UKFB_ERR_INVALID_ARG;
+    if (cycles < 0) return fail(UKFB_ERR_INVALID_ARG, "cycles >= 0");
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    if (cycles == 0) return UKFB_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    // device rings of this call's samples, one slot per cycle: [z | Q | in_a | in_b]
+    const size_t per = size_t(cycles) * size_t(e->cap);
+    const size_t nz = per * 3, nq = per * 9, na = in_a ? per * 3 : 0, nb = in_b ? per * 3 : 0;
+    const size_t bytes = (nz + nq + na + nb) * e->tsize;
+    if (e->multi_bytes < bytes) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->multi_dev) HIP_TRY(hipFree(e->multi_dev));
+        e->multi_dev = nullptr;
+        e->multi_bytes = 0;
+        HIP_TRY(hipMalloc(&e->multi_dev, bytes));
+        e->multi_bytes = bytes;
+    }
+    char* base = static_cast<char*>(e->multi_dev);
+    void* z_dev = base;
+    void* Q_dev = base + nz * e->tsize;
+    void* a_dev = in_a ? base + (nz + nq) * e->tsize : nullptr;
+    void* b_dev = in_b ? base + (nz + nq + na) * e->tsize : nullptr;
+    int rc = upload(e, z_dev, 0, z, nz);
+    if (!rc) rc = upload(e, Q_dev, 0, Q, nq);
+    if (!rc && in_a) rc = upload(e, a_dev, 0, in_a, na);
+    if (!rc && in_b) rc = upload(e, b_dev, 0, in_b, nb);
+    if (rc) return rc;
+    return ukfb_cycle_multi_dev(e, cycles, dt, meas_model, cycles, 0, a_dev, b_dev, z_dev, Q_dev);
 }
 
 int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q) {

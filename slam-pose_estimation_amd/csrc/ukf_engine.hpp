@@ -54,6 +54,9 @@ struct ukfb_engine {
     // fp32 engines: device scratch for host doubles that are narrowed on the device (grow-only)
     void* cvt_dev = nullptr;
     size_t cvt_bytes = 0;
+    // ukfb_cycle_multi: device rings of the host samples of one call (grow-only)
+    void* multi_dev = nullptr;
+    size_t multi_bytes = 0;
     // ukfb_process_events: device workspace (grow-only)
     void* ev_dev = nullptr;
     size_t ev_bytes = 0;

@@ -42,7 +42,7 @@ EXPORTS = [
     "ukfb_pose_set_acceleration", "ukfb_pose_bind_acceleration_dev", "ukfb_orient_set_params",
     "ukfb_orient_set_inputs", "ukfb_orient_bind_inputs_dev", "ukfb_orient_get_rotation_rate", "ukfb_predict",
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
-    "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_cycle_multi_dev",
+    "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_cycle_multi_dev", "ukfb_cycle_multi",
     "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
     "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
@@ -304,6 +304,18 @@ class BatchUKF:
         _chk(self._lib.ukfb_cycle_multi_dev(self._h, C.c_int(cycles), C.c_double(dt), C.c_int(meas_model), C.c_int(slots),
                                             C.c_int(first_slot), _devptr(in_a_dev), _devptr(in_b_dev), _devptr(z_dev),
                                             _devptr(Q_dev)), "ukfb_cycle_multi_dev")
+
+    def cycle_multi(self, dt: float, meas_model: int, z, Q, in_a=None, in_b=None):
+        """Host arrays, one input set per cycle: z [cycles, capacity, 3], Q [cycles, capacity, 3, 3], in_a / in_b
+        [cycles, capacity, 3] or None (the latched inputs); all cycles in one launch."""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        cycles = z.shape[0]
+        z = _f64(z, (cycles, self.capacity, 3)); Q = _f64(Q, (cycles, self.capacity, 3, 3))
+        a = None if in_a is None else _f64(in_a, (cycles, self.capacity, 3))
+        b = None if in_b is None else _f64(in_b, (cycles, self.capacity, 3))
+        _chk(self._lib.ukfb_cycle_multi(self._h, C.c_int(cycles), C.c_double(dt), C.c_int(meas_model),
+                                        _pd(a) if a is not None else None, _pd(b) if b is not None else None, _pd(z), _pd(Q)),
+             "ukfb_cycle_multi")
 
     def cycle_timestamps(self, ts_us, meas_model, z, Q):
         """Fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]); ts < 0: no sample."""

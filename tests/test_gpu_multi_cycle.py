@@ -165,3 +165,28 @@ def test_multi_cycle_status_is_the_or_over_cycles_and_failures_skip(spe):
         e.cycle_multi_dev(2, 0.01, spe.MEAS_POS3, z_r, Q_r, 1, first_slot=1)
     with pytest.raises(spe.UkfbError):
         e.cycle_multi_dev(2, 0.01, spe.MEAS_ORIENT_BODYVEL3, z_r, Q_r, 1)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_host_pointer_multi_cycle(spe, prec):
+    """ukfb_cycle_multi: host doubles, one input set per cycle, uploaded to an engine-owned ring; equals single cycles"""
+    s = spe.synth
+    cycles = 5
+    mu, cov = s.pose_initial(N)
+    ins = [s.pose_cycle_inputs(N, k, mu[:, :3]) for k in range(cycles)]
+    acc = np.stack([i[0] for i in ins]); z = np.stack([i[1] for i in ins]); Q = np.stack([i[2] for i in ins])
+
+    def engine():
+        e = spe.BatchPoseUKF(N, precision=prec)
+        e.initialize(mu, cov)
+        e.set_acceleration(None, 0.01 * np.eye(3))
+        return e
+    a, b = engine(), engine()
+    for c in range(cycles):
+        a.set_acceleration(acc[c], None)
+        a.cycle(0.01, spe.MEAS_POS3, z[c], Q[c])
+    b.cycle_multi(0.01, spe.MEAS_POS3, z, Q, in_a=acc)
+    assert np.array_equal(a.state()[0], b.state()[0]) and np.array_equal(a.state()[1], b.state()[1])
+    assert (b.status() == 0).all()
+    b.cycle_multi(0.01, spe.MEAS_POS3, z[:2], Q[:2])      # shorter call, latched acceleration (the ring is reused)
+    assert (b.status() == 0).all()

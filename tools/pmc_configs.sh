@@ -6,17 +6,23 @@
 #   - two SQ passes: VALU instructions by class (FMA / MUL / ADD / TRANS per precision, INT32, INT64, CVT) for the weighted issue model
 #   - rocprofv3 --kernel-trace --stats of the default bench command
 # Output: gpurun_out/pmc_configs/{traffic_latest.json,pmc_latest.json,*_kernel_stats.csv,summary.txt}
-# usage: tools/pmc_configs.sh [tag]        (copy the json / csv files into profiles/ afterwards)
+# usage: tools/pmc_configs.sh [tag] [part]   part = all | 1 | 2: a gpurun call is limited to 20 minutes, the whole set takes
+#        about 25 -- run parts 1 and 2 in two calls (their outputs merge in gpurun_out/pmc_configs) and then
+#        `python3 tools/pmc_report.py gpurun_out/pmc_configs <tag>` in the container; copy the json / csv files into profiles/
 set -u
 tag=${1:-r02}
-out=$PWD/gpurun_out/pmc_configs; rm -rf $out; mkdir -p $out
+part=${2:-all}
+out=$PWD/gpurun_out/pmc_configs; mkdir -p $out
 export TMPDIR=/tmp
+if [ $part != 2 ]; then
 hipcc -O2 --offload-arch=gfx950 tools/calib_traffic.hip -o $out/calib_traffic || exit 1
 for prec in f64 f32; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/calib_${prec}_$c -- $out/calib_traffic 1048576 $prec > $out/calib_${prec}_$c.json 2> $out/calib_${prec}_$c.err
   done
 done
+rm -f $out/calib_traffic
+fi
 B="--steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-extra-regions"
 cfg() {  # name, bench args
   name=$1; shift
@@ -28,16 +34,19 @@ cfg() {  # name, bench args
     echo "$name $p rc=$?"
   done
 }
+if [ $part != 2 ]; then
 cfg headline_f64
 cfg headline_f32 --precision f32
 cfg cfg2 --filters 65536
 cfg cfg3 --filters 131072 --precision f32
+cfg multi8_f64 --cycles-per-launch 8 --warmup 16
+fi
+if [ $part = 1 ]; then exit 0; fi
 cfg cfg4 --workload orient --precision f32 --filters 4194304
 cfg cfg5 --workload pose-mixed --filters 262144
-cfg multi8_f64 --cycles-per-launch 8 --warmup 16
 cfg multi8_f32 --cycles-per-launch 8 --warmup 16 --precision f32
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --filters 65536 > $out/trace_cfg2.json 2> $out/trace_cfg2.err
 # kernel stats of the default command (the driver's own invocation and the 500-step default)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions > $out/trace_default.json 2> $out/trace_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --precision f32 > $out/trace_f32.json 2> $out/trace_f32.err
-python3 tools/pmc_report.py $out $tag | tee $out/summary.txt
+if [ $part = all ]; then python3 tools/pmc_report.py $out $tag | tee $out/summary.txt; fi

@@ -31,6 +31,10 @@
 //  * every per-filter stream is requested in the prologue, before the first dependent instruction.
 //  * indirect launches (KArgs::fidx): work item i acts on filter fidx[i]; event streams launch each round over
 //    exactly the filters that have a sample in it.
+//  * lane constants of the prediction's covariance phase (which tile, operand and result offsets) come from a compile-time
+//    table in the Pose kernels (CovTab) instead of being decoded by every wavefront.
+//  * multi-cycle launches (MULTI): C fused cycles in one launch, the filter stays in LDS between them; bit-identical with C
+//    single launches, the per-cycle inputs come from device rings.
 //  * LDS per filter (Layout16): factor columns (stride 14) aliased by the delta table and the fp64 transposition,
 //    packed-covariance staging, affine factor rows, 56 scalars of mean / rotation / z, Q / store sink.
 //

@@ -116,7 +116,38 @@ int main()
         for (int k = 0; k < 14; ++k) dmax = std::fmax(dmax, std::fabs(mu3[i * 14 + k] - ms[k]));
         for (int k = 0; k < 169; ++k) dmax = std::fmax(dmax, std::fabs(cov3[i * 169 + k] - Ps.data()[k]));
     }
-    std::printf("\"batch_orient_vs_scalar\": %.3g, \"batch_orient_dvz\": %.3g\n", dmax, mu3[6] - mu0[6]);
+    std::printf("\"batch_orient_vs_scalar\": %.3g, \"batch_orient_dvz\": %.3g,\n", dmax, mu3[6] - mu0[6]);
+
+    // ---------------- BatchOrientationUKF::cycles (several buffered IMU + velocity samples in ONE launch) against the same
+    // samples applied one cycle() at a time: the state must agree bit for bit
+    {
+        const int C = 3, NB = 3;
+        double gyro[C * NB * 3], accs[C * NB * 3], zz[C * NB * 3], QQ[C * NB * 9];
+        for (int c = 0; c < C; ++c)
+            for (int i = 0; i < NB; ++i) {
+                const int o = c * NB + i;
+                gyro[o * 3 + 0] = 0.01 * (c + 1); gyro[o * 3 + 1] = -0.02; gyro[o * 3 + 2] = 0.05 * (i + 1);
+                accs[o * 3 + 0] = 0.1 * i; accs[o * 3 + 1] = -0.05 * c; accs[o * 3 + 2] = 9.79;
+                zz[o * 3 + 0] = 0.09; zz[o * 3 + 1] = 0.03 * c; zz[o * 3 + 2] = -0.04 * i;
+                for (int k = 0; k < 9; ++k) QQ[o * 9 + k] = (k % 4 == 0) ? 0.0025 : 0.0;
+            }
+        BatchOrientationUKF one(NB, 3600.0, 1800.0, earth), many(NB, 3600.0, 1800.0, earth);
+        double mi[NB * 14], ci[NB * 169];
+        for (int i = 0; i < NB; ++i) { for (int k = 0; k < 14; ++k) mi[i * 14 + k] = mu0[k]; for (int k = 0; k < 169; ++k) ci[i * 169 + k] = Q0.data()[k]; }
+        one.setProcessNoiseCovariance(Rn.data()); many.setProcessNoiseCovariance(Rn.data());
+        one.initializeFilters(0, NB, mi, ci); many.initializeFilters(0, NB, mi, ci);
+        for (int c = 0; c < C; ++c) {
+            one.setInputs(0, NB, gyro + c * NB * 3, accs + c * NB * 3);
+            one.cycle(0.01, UKFB_MEAS_ORIENT_BODYVEL3, zz + c * NB * 3, QQ + c * NB * 9);
+        }
+        many.cycles(C, 0.01, UKFB_MEAS_ORIENT_BODYVEL3, accs, gyro, zz, QQ);
+        double ma[NB * 14], ca[NB * 169], mb[NB * 14], cb[NB * 169];
+        one.getCurrentStates(0, NB, ma, ca); many.getCurrentStates(0, NB, mb, cb);
+        bool same = true;
+        for (int k = 0; k < NB * 14; ++k) same = same && ma[k] == mb[k];
+        for (int k = 0; k < NB * 169; ++k) same = same && ca[k] == cb[k];
+        std::printf("\"batch_cycles_bit_equal\": %s\n", same ? "true" : "false");
+    }
     std::printf("}\n");
     return 0;
 }

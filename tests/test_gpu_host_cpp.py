@@ -31,6 +31,7 @@ def test_host_cpp_classes_match_the_oracle(oracle, onp):
     assert r["pose_ok"] and r["threw_negative"] and r["threw_nonfinite"] and r["state_size"] == 12
     # C++ BatchOrientationUKF latches the constructor's inputs: equal to the scalar class, velocity held steady
     assert r["batch_orient_vs_scalar"] <= 1e-12 and abs(r["batch_orient_dvz"]) < 1e-3
+    assert r["batch_cycles_bit_equal"] is True      # BatchUKF::cycles (one launch) == the same samples one cycle() at a time
     # ---- PoseUKF sequence restated with the oracle
     mu = np.array([[1.0, -2.0, 0.5, 0.0, 0.3826834323650898, 0.0, 0.9238795325112867, 0.3, 0.1, -0.2, 0.05, -0.02, 0.1]])
     i, j = np.meshgrid(np.arange(12), np.arange(12), indexing="ij")

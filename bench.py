@@ -562,7 +562,8 @@ def run_rank(args):
         traffic_e, exact = load_profile_entry("traffic_latest.json", info["kernel"], per)
         traffic = None
         # a multi-cycle entry holds per-launch counters of its own cycles per launch: only the same launch shape is comparable
-        same_shape = lambda e: e is not None and abs(float(e.get("cycles_per_launch", 1.0)) - cycles_launch) < 1e-9   # noqa: E731
+        # (a run whose K is no multiple of C ends with one shorter launch: the nominal shape decides)
+        same_shape = lambda e: e is not None and abs(float(e.get("cycles_per_launch", 1.0)) - cpl[0]) < 1e-9   # noqa: E731
         if same_shape(traffic_e):   # bytes per launch scale with the filters of the launch (per-filter streams only)
             traffic = float(traffic_e["hbm_bytes_per_launch"]) * (1.0 if exact else per / float(traffic_e["filters_per_launch"]))
         pmc_e, _ = load_profile_entry("pmc_latest.json", info["kernel"], per)

@@ -974,6 +974,55 @@ int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, 
     return launch(e, r);
 }
 
+int ukfb_cycle_schedule_dev(ukfb_engine* e, int cycles, const double* dt, const int32_t* meas_model, int slots, int first_slot,
+                            const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev) {
+    if (!e || !dt || !meas_model || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    if (cycles < 0 || slots < 1 || first_slot < 0 || first_slot >= slots)
+        return fail(UKFB_ERR_INVALID_ARG, "cycles >= 0, slots >= 1, 0 <= first_slot < slots");
+    for (int c = 0; c < cycles; ++c)
+        if (meas_model[c] >= 0 && !meas_model_ok(e, meas_model[c]))
+            return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    const bool tuned = e->cfg.lanes_per_filter == 16;
+    const size_t w = e->tsize;
+    const void* keep_a = e->in_a_bound;
+    const void* keep_b = e->in_b_bound;
+    int rc = UKFB_OK;
+    // the tuned layout: launches of up to UKFB_MAX_MULTI_CYCLES cycles, the schedule travels in the kernel arguments;
+    // the one-wavefront-per-filter layouts: one launch per cycle
+    const int chunk = tuned ? UKFB_MAX_MULTI_CYCLES : 1;
+    for (int c0 = 0; c0 < cycles && rc == UKFB_OK; c0 += chunk) {
+        const int nc = (cycles - c0 < chunk) ? (cycles - c0) : chunk;
+        ukfb::LaunchReq r;
+        r.do_predict = true;
+        r.status_accumulate = c0 > 0;         // the status word is the OR over ALL cycles of the call
+        if (tuned) {
+            r.do_update = true;
+            r.z_dev = z_dev;
+            r.Q_dev = Q_dev;
+            r.cycles = nc;
+            r.slots = slots;
+            r.first_slot = (first_slot + c0) % slots;
+            r.in_a_slots = in_a_dev;
+            r.in_b_slots = in_b_dev;
+            r.sched_dt = dt + c0;
+            r.sched_model = meas_model + c0;
+        } else {
+            const size_t s = size_t((first_slot + c0) % slots) * size_t(e->cap);
+            if (in_a_dev) e->in_a_bound = static_cast<const char*>(in_a_dev) + s * 3 * w;
+            if (in_b_dev) e->in_b_bound = static_cast<const char*>(in_b_dev) + s * 3 * w;
+            r.do_update = meas_model[c0] >= 0;
+            r.dt_uniform = dt[c0];
+            r.meas_uniform = meas_model[c0];
+            r.z_dev = static_cast<const char*>(z_dev) + s * 3 * w;
+            r.Q_dev = static_cast<const char*>(Q_dev) + s * 9 * w;
+        }
+        rc = launch(e, r);
+    }
+    e->in_a_bound = keep_a;
+    e->in_b_bound = keep_b;
+    return rc;
+}
+
 int ukfb_cycle_multi(ukfb_engine* e, int cycles, double dt, int meas_model, const double* in_a, const double* in_b,
                      const double* z, const double* Q) {
     if (!e || !z || !Q) return UKFB_ERR_INVALID_ARG;

@@ -10,6 +10,10 @@
 
 #include "../../include/ukf_batch.h"
 
+#ifndef UKFB_MAX_MULTI_CYCLES
+#define UKFB_MAX_MULTI_CYCLES 32   // cycles of one multi-cycle launch with a schedule (the host splits longer ones)
+#endif
+
 struct ukfb_engine {
     int model = 0, prec = 0, device = 0;
     int64_t cap = 0;
@@ -89,6 +93,8 @@ struct LaunchReq {
     int cycles = 0, first_slot = 0, slots = 1;
     const void* in_a_slots = nullptr;
     const void* in_b_slots = nullptr;
+    const double* sched_dt = nullptr;        // host, [cycles]: per-cycle time steps and models (both or neither)
+    const int32_t* sched_model = nullptr;
 };
 
 int launch_pose_f64(ukfb_engine* e, const LaunchReq& r);

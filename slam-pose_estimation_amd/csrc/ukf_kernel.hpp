@@ -36,6 +36,9 @@ enum : uint32_t {
     ST_REJECTED_GATE = 1u << 9,
 };
 
+#ifndef UKFB_MAX_MULTI_CYCLES
+#define UKFB_MAX_MULTI_CYCLES 32   // (also in ukf_engine.hpp, for the host side)
+#endif
 template <class T> struct KArgs {
     int64_t n;                   // work items of this launch (= filters, or entries of fidx)
     // Indirect launch (event streams): work item i acts on filter fidx[i]; the per-call inputs (ts, dt, meas, active,
@@ -79,6 +82,11 @@ template <class T> struct KArgs {
     // the latched inputs serve every cycle.  Single-cycle launches leave all of this zero.
     int cyc_count, cyc_first, cyc_ring, cyc_in;
     int64_t cyc_items;
+    // per-cycle schedule (cyc_sched != 0): time step and measurement model of cycle c instead of dt_uniform / meas_uniform;
+    // a negative model = prediction only in that cycle.  Launch-wide scalars: the kernel reads them with scalar loads.
+    int cyc_sched;
+    int32_t cyc_model[UKFB_MAX_MULTI_CYCLES];
+    double cyc_dt[UKFB_MAX_MULTI_CYCLES];
 #ifdef UKFB_STAMPS
     unsigned long long* stamps;  // diagnostic build: [grid][UKFB_MAX_STAMPS] s_memtime per phase marker
 #endif

@@ -757,8 +757,8 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
         has_ctr = l == D;
         // the same for the two launch-wide scalars whose derivatives (time gate, selection tables of the measurement
         // model) are evaluated with vector instructions: opaque scalar moves
-        dt_uniform_c = a.dt_uniform;
-        meas_uniform_c = a.meas_uniform;
+        dt_uniform_c = a.cyc_sched ? a.cyc_dt[cyc] : a.dt_uniform;          // (a schedule: this cycle's own dt and model)
+        meas_uniform_c = a.cyc_sched ? a.cyc_model[cyc] : a.meas_uniform;
         asm volatile("" : "+s"(dt_uniform_c));
         asm volatile("" : "+s"(meas_uniform_c));
     }
@@ -829,7 +829,9 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
         mid = a.meas ? mid_l : meas_uniform_c;
         const bool act = M::meas_valid(mid) && (a.active ? act_b != 0 : true);
         do_u = live && act && !p_error && !noev;
-        st |= (live && !do_u) ? ST_INACTIVE : 0u;
+        // (a scheduled prediction-only cycle of a multi-cycle launch is a plain predictionStep: no INACTIVE mark)
+        const bool predict_only = MULTI && a.cyc_sched != 0 && meas_uniform_c < 0;
+        st |= (live && !do_u && !predict_only) ? ST_INACTIVE : 0u;
     }
     wsync();
     if constexpr (DO_PREDICT) {

@@ -166,6 +166,13 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
         a.cyc_in = (r.in_a_slots ? 1 : 0) | (r.in_b_slots ? 2 : 0);
         if (r.in_a_slots) a.in_a = static_cast<const T*>(r.in_a_slots);
         if (r.in_b_slots) a.in_b = static_cast<const T*>(r.in_b_slots);
+        if (r.sched_dt && r.sched_model) {
+            a.cyc_sched = 1;
+            for (int c = 0; c < r.cycles && c < UKFB_MAX_MULTI_CYCLES; ++c) {
+                a.cyc_dt[c] = r.sched_dt[c];
+                a.cyc_model[c] = r.sched_model[c];
+            }
+        }
     }
     switch (e->cfg.lanes_per_filter) {
         case 64: return launch_g<T, M, 64>(e, r, a);

@@ -190,3 +190,62 @@ def test_host_pointer_multi_cycle(spe, prec):
     assert (b.status() == 0).all()
     b.cycle_multi(0.01, spe.MEAS_POS3, z[:2], Q[:2])      # shorter call, latched acceleration (the ring is reused)
     assert (b.status() == 0).all()
+
+
+@pytest.mark.parametrize("G", [16, 64])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_scheduled_multi_cycle(spe, oracle, prec, G):
+    """ukfb_cycle_schedule_dev: every cycle its own dt and measurement model, negative = prediction only -- an IMU-rate
+    filter with slower aiding sensors replayed from a buffer (40 cycles = two launches of the tuned kernel).  Against the
+    same sequence as single launches (predict / fused cycle) and against the oracle."""
+    s = spe.synth
+    rng = np.random.default_rng(5)
+    slots, cycles = 8, 40
+    mu, cov = s.pose_initial(N)
+    ins = [s.pose_cycle_inputs(N, k, mu[:, :3], random_q=True) for k in range(slots)]
+    acc_r = _rings([i[0] for i in ins], prec)
+    Q_r = _rings([i[2].reshape(N, 9) for i in ins], prec)
+    # measurement values per slot: position-like numbers are fine for every 3-vector model (the filter just follows them)
+    z_host = [0.1 * i[1] for i in ins]
+    z_r = _rings(z_host, prec)
+    dts = rng.uniform(0.005, 0.02, cycles)
+    models = np.full(cycles, -1, dtype=np.int32)
+    models[4::5] = spe.MEAS_VEL3            # every 5th cycle a velocity sample
+    models[9::10] = spe.MEAS_POS3           # every 10th a position fix instead
+    models[17] = spe.MEAS_ANGVEL3
+    acc_cov = 0.01 * np.eye(3)
+
+    def engine():
+        e = spe.BatchPoseUKF(N, precision=prec, lanes_per_filter=G)
+        e.initialize(mu, cov)
+        e.set_acceleration(None, acc_cov)
+        return e
+    a = engine()
+    for c in range(cycles):
+        k = c % slots
+        a.bind_acceleration_dev(acc_r[k])
+        if models[c] < 0:
+            a.predict(float(dts[c]))
+        else:
+            a.cycle_dev(float(dts[c]), int(models[c]), z_r[k], Q_r[k])
+    a.sync()
+    b = engine()
+    b.cycle_schedule_dev(dts, models, z_r, Q_r, slots, 0, in_a_dev=acc_r)
+    b.sync()
+    ma, ca, _ = a.state()
+    mb, cb, _ = b.state()
+    # the prediction-only launches of `a` are another kernel instantiation than the fused one: equal up to rounding
+    tight = 1e-12 if prec == 0 else 2e-5
+    assert max_abs(ma, mb) <= tight and max_abs(ca, cb) <= tight
+    assert (b.status() == 0).all()          # prediction-only cycles are plain predictionSteps: no INACTIVE mark
+    cast = (lambda x: x) if prec == 0 else (lambda x: x.astype(np.float32).astype(np.float64))
+    m_o, c_o = mu.copy(), cov.copy()
+    R = s.pose_default_process_noise()
+    for c in range(cycles):
+        k = c % slots
+        m_o, c_o, _ = oracle.pose_predict(m_o, c_o, R, cast(ins[k][0]), acc_cov, float(dts[c]))
+        if models[c] >= 0:
+            m_o, c_o, _ = oracle.pose_update(m_o, c_o, np.full(N, models[c], dtype=np.int32), cast(z_host[k]), cast(ins[k][2]))
+    assert max_abs(mb, m_o) <= TOL[prec] and max_abs(cb, c_o) <= TOL[prec]
+    with pytest.raises(spe.UkfbError):
+        b.cycle_schedule_dev([0.01], [spe.MEAS_ORIENT_BODYVEL3], z_r, Q_r, slots)

@@ -375,7 +375,8 @@ def run_rank(args):
     gyr_d = [gyr_ring[k] for k in range(N_RING)] if orient else None
     z_d = [z_ring[k] for k in range(N_RING)]
     Q_d = [Q_ring[k] for k in range(N_RING)]
-    m_d = [torch.empty((per,), dtype=torch.int32, device=dev) for _ in range(N_RING)] if args.workload == "pose-mixed" else None
+    m_ring = torch.empty((N_RING, per), dtype=torch.int32, device=dev) if args.workload == "pose-mixed" else None
+    m_d = [m_ring[k] for k in range(N_RING)] if m_ring is not None else None
     for lo in range(0, per, CH):
         hi = min(per, lo + CH)
         if orient:
@@ -405,8 +406,6 @@ def run_rank(args):
 
     cv = args.workload == "pose-cv"   # no acceleration latched (the engine's default is NaN): constant-velocity branch
     cpl = [max(1, args.cycles_per_launch)]   # cycles per launch of run_cycles (the extra multi-cycle region changes it)
-    if cpl[0] > 1 and m_d is not None:
-        raise SystemExit("--cycles-per-launch > 1 needs one measurement model for the batch (not --workload pose-mixed)")
 
     def step():
         r = done[0] % N_RING
@@ -431,6 +430,8 @@ def run_rank(args):
             if orient:
                 eng.cycle_multi_dev(c, DT, spe.MEAS_ORIENT_BODYVEL3, z_ring, Q_ring, N_RING, done[0] % N_RING,
                                     in_a_dev=acc_ring, in_b_dev=gyr_ring)
+            elif m_ring is not None:
+                eng.cycle_multi_mixed_dev(c, DT, m_ring, z_ring, Q_ring, N_RING, done[0] % N_RING, in_a_dev=acc_ring)
             else:
                 eng.cycle_multi_dev(c, DT, spe.MEAS_POS3, z_ring, Q_ring, N_RING, done[0] % N_RING,
                                     in_a_dev=None if cv else acc_ring)
@@ -536,7 +537,7 @@ def run_rank(args):
         time.sleep(1.0)    # let the clocks recover
         burst_ms = kernel_region(BURST_STEPS)
         fence()
-        if cpl[0] == 1 and m_d is None and info["filters_per_workgroup"] == 4:
+        if cpl[0] == 1 and info["filters_per_workgroup"] == 4:
             # the same cycles once more as launches of MULTI_CYCLES cycles (ukfb_cycle_multi_dev): the filters stay in LDS
             # between the cycles of a launch.  Reported beside the headline, never as `value`.
             restore()

@@ -213,7 +213,12 @@ int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int3
  * gated or fails is skipped for that filter as in a single launch, the following cycles still run. */
 int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, int slots, int first_slot,
                          const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev);
-/* the same with a schedule: cycle c predicts by dt[c] and updates with model meas_model[c] (host arrays of `cycles`
+/* the same with per-filter model ids per cycle (the asynchronous mixed stream of BASELINE config 5, buffered):
+ * meas_model_dev is a ring int32 [slots][capacity] like z and Q, negative = no measurement for that filter in that cycle
+ * (prediction only, status INACTIVE as in ukfb_cycle_dev) */
+int ukfb_cycle_multi_mixed_dev(ukfb_engine* e, int cycles, double dt, int slots, int first_slot, const void* in_a_dev,
+                               const void* in_b_dev, const int32_t* meas_model_dev, const void* z_dev, const void* Q_dev);
+/* ukfb_cycle_multi_dev with a schedule: cycle c predicts by dt[c] and updates with model meas_model[c] (host arrays of `cycles`
  * entries; a negative model = prediction only in that cycle, i.e. a plain predictionStep).  One launch per 32 cycles.  This is an IMU-rate filter with slower aiding sensors replayed from a buffer: e.g. ten 100 Hz
  * predictions of which the last one carries a 10 Hz position fix (BASELINE config 2's workload) in one launch. */
 int ukfb_cycle_schedule_dev(ukfb_engine* e, int cycles, const double* dt, const int32_t* meas_model, int slots, int first_slot,

@@ -927,12 +927,14 @@ int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int3
     return launch(e, r);
 }
 
-int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, int slots, int first_slot,
-                         const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev) {
+// meas_dev != NULL: per-filter model ids, a ring [slots][capacity] like z and Q (meas_model is then ignored)
+static int cycle_multi_impl(ukfb_engine* e, int cycles, double dt, int meas_model, const int32_t* meas_dev, int slots,
+                            int first_slot, const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev) {
     if (!e || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
     if (cycles < 0 || slots < 1 || first_slot < 0 || first_slot >= slots)
         return fail(UKFB_ERR_INVALID_ARG, "cycles >= 0, slots >= 1, 0 <= first_slot < slots");
-    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    if (!meas_dev && !meas_model_ok(e, meas_model))
+        return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
     if (cycles == 0) return UKFB_OK;
     if (e->cfg.lanes_per_filter != 16) {
         // the one-wavefront-per-filter layouts have no multi-cycle kernel: one launch per cycle, same results.  The
@@ -950,6 +952,7 @@ int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, 
             r.do_update = true;
             r.dt_uniform = dt;
             r.meas_uniform = meas_model;
+            r.meas_dev = meas_dev ? meas_dev + s : nullptr;
             r.z_dev = static_cast<const char*>(z_dev) + s * 3 * w;
             r.Q_dev = static_cast<const char*>(Q_dev) + s * 9 * w;
             r.status_accumulate = c > 0;
@@ -964,6 +967,7 @@ int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, 
     r.do_update = true;
     r.dt_uniform = dt;
     r.meas_uniform = meas_model;
+    r.meas_dev = meas_dev;
     r.z_dev = z_dev;
     r.Q_dev = Q_dev;
     r.cycles = cycles;
@@ -972,6 +976,17 @@ int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, 
     r.in_a_slots = in_a_dev;
     r.in_b_slots = in_b_dev;
     return launch(e, r);
+}
+
+int ukfb_cycle_multi_dev(ukfb_engine* e, int cycles, double dt, int meas_model, int slots, int first_slot,
+                         const void* in_a_dev, const void* in_b_dev, const void* z_dev, const void* Q_dev) {
+    return cycle_multi_impl(e, cycles, dt, meas_model, nullptr, slots, first_slot, in_a_dev, in_b_dev, z_dev, Q_dev);
+}
+
+int ukfb_cycle_multi_mixed_dev(ukfb_engine* e, int cycles, double dt, int slots, int first_slot, const void* in_a_dev,
+                               const void* in_b_dev, const int32_t* meas_model_dev, const void* z_dev, const void* Q_dev) {
+    if (!meas_model_dev) return UKFB_ERR_INVALID_ARG;
+    return cycle_multi_impl(e, cycles, dt, -1, meas_model_dev, slots, first_slot, in_a_dev, in_b_dev, z_dev, Q_dev);
 }
 
 int ukfb_cycle_schedule_dev(ukfb_engine* e, int cycles, const double* dt, const int32_t* meas_model, int slots, int first_slot,

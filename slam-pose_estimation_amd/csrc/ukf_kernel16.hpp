@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
         // multi-cycle launches are direct launches with one dt and one measurement model for every filter (checked by the
         // host): no per-filter timestamps, time steps, model ids, activity flags or filter index list to keep alive
         __builtin_assume(a.fidx == nullptr); __builtin_assume(a.ts == nullptr); __builtin_assume(a.dt == nullptr);
-        __builtin_assume(a.meas == nullptr); __builtin_assume(a.active == nullptr);
+        __builtin_assume(a.active == nullptr);   // (per-filter model ids are allowed: a ring like z and Q, negative = none)
     }
     const int lane = threadIdx.x;
     // (not const: a multi-cycle launch re-derives everything that follows from the lane index in every cycle, see below)
@@ -679,8 +679,12 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     const T mu_l = a.mu[fc * S + ((l < S) ? l : (S - 1))];
     ProcIn<T> pin;
     // per-call inputs of one input slot (single-cycle launches: slot 0 = the arrays themselves)
-    const auto load_inputs = [&](int slot, T (&ia)[3], T (&ib)[3], T& zq) {
+    const auto load_inputs = [&](int slot, T (&ia)[3], T (&ib)[3], T& zq, int32_t& mid_slot) {
         const int64_t so = MULTI ? int64_t(slot) * a.cyc_items : 0;
+        if constexpr (DO_UPDATE) {
+            const int32_t* mp = a.meas ? (a.meas + so + fi) : reinterpret_cast<const int32_t*>(a.status + fc);
+            mid_slot = *mp;
+        }
         if constexpr (DO_PREDICT) {
             // latched inputs: the engine always passes both arrays (its own or the bound ones)
             const T* pa = a.in_a + ((MULTI && (a.cyc_in & 1)) ? so + fc : fc) * 3;
@@ -699,7 +703,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     T zq_l = T(0);
     int slot = MULTI ? a.cyc_first : 0;
     if constexpr (MULTI) {
-        load_inputs(slot, pin.a, pin.w, zq_l);
+        load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
     } else {
         if constexpr (DO_PREDICT) {
             const T* pa = a.in_a + fc * 3;
@@ -766,14 +770,15 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     // arithmetic, into registers.  fp32 (6 per SIMD, issue-bound, 3 registers from its budget): every cycle loads its own.
     constexpr bool PREFETCH = MULTI && sizeof(T) == 8;
     T nx_a[3] = {T(0), T(0), T(0)}, nx_w[3] = {T(0), T(0), T(0)}, nx_zq = T(0);
+    int32_t nx_mid = 0;
     if constexpr (MULTI) {
         if constexpr (PREFETCH) {   // (the last cycle re-reads its own slot)
             const int nslot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
             slot = (cyc + 1 < ncyc) ? nslot : slot;
-            load_inputs(slot, nx_a, nx_w, nx_zq);
+            load_inputs(slot, nx_a, nx_w, nx_zq, nx_mid);
         } else if (cyc > 0) {
             slot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
-            load_inputs(slot, pin.a, pin.w, zq_l);
+            load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
         }
     }
     if constexpr (DO_UPDATE) ZQ[(l < 12) ? l : (LY::DUM - LY::ZQ)] = zq_l;
@@ -1780,6 +1785,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             pin.w[k] = nx_w[k];
         }
         zq_l = nx_zq;
+        mid_l = nx_mid;
     }
     } while (MULTI && ++cyc < ncyc);   // cycles
 

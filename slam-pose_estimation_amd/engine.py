@@ -43,7 +43,7 @@ EXPORTS = [
     "ukfb_orient_set_inputs", "ukfb_orient_bind_inputs_dev", "ukfb_orient_get_rotation_rate", "ukfb_predict",
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
     "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_cycle_multi_dev", "ukfb_cycle_multi",
-    "ukfb_cycle_schedule_dev",
+    "ukfb_cycle_schedule_dev", "ukfb_cycle_multi_mixed_dev",
     "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
     "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
@@ -305,6 +305,13 @@ class BatchUKF:
         _chk(self._lib.ukfb_cycle_multi_dev(self._h, C.c_int(cycles), C.c_double(dt), C.c_int(meas_model), C.c_int(slots),
                                             C.c_int(first_slot), _devptr(in_a_dev), _devptr(in_b_dev), _devptr(z_dev),
                                             _devptr(Q_dev)), "ukfb_cycle_multi_dev")
+
+    def cycle_multi_mixed_dev(self, cycles: int, dt: float, meas_model_dev, z_dev, Q_dev, slots: int, first_slot: int = 0,
+                              in_a_dev=None, in_b_dev=None):
+        """cycle_multi_dev with per-filter model ids per cycle: meas_model_dev int32 [slots][capacity], negative = none."""
+        _chk(self._lib.ukfb_cycle_multi_mixed_dev(self._h, C.c_int(cycles), C.c_double(dt), C.c_int(slots), C.c_int(first_slot),
+                                                  _devptr(in_a_dev), _devptr(in_b_dev), _devptr(meas_model_dev),
+                                                  _devptr(z_dev), _devptr(Q_dev)), "ukfb_cycle_multi_mixed_dev")
 
     def cycle_schedule_dev(self, dt, meas_model, z_dev, Q_dev, slots: int, first_slot: int = 0, in_a_dev=None, in_b_dev=None):
         """Scheduled multi-cycle launch: cycle c predicts by dt[c] and updates with model meas_model[c] (negative: prediction

@@ -249,3 +249,51 @@ def test_scheduled_multi_cycle(spe, oracle, prec, G):
     assert max_abs(mb, m_o) <= TOL[prec] and max_abs(cb, c_o) <= TOL[prec]
     with pytest.raises(spe.UkfbError):
         b.cycle_schedule_dev([0.01], [spe.MEAS_ORIENT_BODYVEL3], z_r, Q_r, slots)
+
+
+@pytest.mark.parametrize("G", [16, 32])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_mixed_model_multi_cycle(spe, oracle, prec, G):
+    """ukfb_cycle_multi_mixed_dev: per-filter model ids per cycle (BASELINE config 5's stream, buffered), negative = none"""
+    import torch
+    s = spe.synth
+    slots, cycles = 4, 6
+    mu, cov = s.pose_initial(N)
+    acc_cov = 0.01 * np.eye(3)
+    ins, mods = [], []
+    for k in range(slots):
+        acc, z, Q = s.pose_cycle_inputs(N, k, mu[:, :3], random_q=True)
+        models = s.pose_mixed_models(N, k)
+        z = s.pose_measurement_for_model(mu, models, z - mu[:, :3])
+        ins.append((acc, z, Q)); mods.append(models)
+    acc_r = _rings([i[0] for i in ins], prec)
+    z_r = _rings([i[1] for i in ins], prec)
+    Q_r = _rings([i[2].reshape(N, 9) for i in ins], prec)
+    m_r = torch.from_numpy(np.stack(mods).astype(np.int32)).cuda().contiguous()
+
+    def engine():
+        e = spe.BatchPoseUKF(N, precision=prec, lanes_per_filter=G)
+        e.initialize(mu, cov)
+        e.set_acceleration(None, acc_cov)
+        return e
+    a = engine()
+    st_or = np.zeros(N, dtype=np.uint32)
+    for c in range(cycles):
+        k = c % slots
+        a.bind_acceleration_dev(acc_r[k])
+        a.cycle_dev(0.01, spe.MEAS_POS3, z_r[k], Q_r[k], meas_model_dev=m_r[k])
+        st_or |= a.status()
+    b = engine()
+    b.cycle_multi_mixed_dev(cycles, 0.01, m_r, z_r, Q_r, slots, 0, in_a_dev=acc_r)
+    ma, ca, _ = a.state()
+    mb, cb, _ = b.state()
+    assert np.array_equal(ma, mb) and np.array_equal(ca, cb)
+    assert (b.status() == st_or).all()                 # OR over the cycles, INACTIVE where a filter had no sample
+    cast = (lambda x: x) if prec == 0 else (lambda x: x.astype(np.float32).astype(np.float64))
+    m_o, c_o = mu.copy(), cov.copy()
+    R = s.pose_default_process_noise()
+    for c in range(cycles):
+        acc, z, Q = ins[c % slots]
+        m_o, c_o, _ = oracle.pose_predict(m_o, c_o, R, cast(acc), acc_cov, 0.01)
+        m_o, c_o, _ = oracle.pose_update(m_o, c_o, mods[c % slots], cast(z), cast(Q))
+    assert max_abs(mb, m_o) <= TOL[prec] and max_abs(cb, c_o) <= TOL[prec]

@@ -15,6 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
+import torch  # noqa: E402,F401  (before the engine library: one HIP runtime per process; the multi-cycle scenarios use device rings)
 import slam_pose_estimation_amd as spe  # noqa: E402
 from oracle import capi as oracle  # noqa: E402
 
@@ -189,6 +190,63 @@ def orient_scenario(rng, k, fails):
         m_f, c_f = m_g.copy(), c_g.copy()
 
 
+def multi_scenario(rng, k, fails):
+    """Multi-cycle launches (ukfb_cycle_multi_dev / ukfb_cycle_schedule_dev / ukfb_cycle_multi_mixed_dev) against the same
+    cycles as single launches of a twin engine (which the scenarios above hold to the oracle): state to rounding (the
+    prediction-only launches of the twin are another kernel instantiation), status word = OR over the cycles."""
+    n = int(rng.choice([1, 3, 4, 5, 17, 64, 131]))
+    prec = int(rng.integers(0, 2))
+    tdt = torch.float64 if prec == 0 else torch.float32
+    mu, cov = spe.synth.pose_initial(n, seed=3000 + k)
+    overall = 10.0 ** rng.uniform(-6, 0.0, n)
+    for i in range(n):
+        cov[i] *= overall[i]
+    if rng.uniform() < 0.3:
+        cov[int(rng.integers(0, n))] = -np.eye(12)            # a filter whose predictions fail in every cycle
+    ctx = f"multi k={k} n={n} prec={'f64' if prec == 0 else 'f32'}"
+    slots = int(rng.integers(1, 6)); cycles = int(rng.integers(1, 8)); first = int(rng.integers(0, slots))
+    acc = rng.uniform(-2, 2, (slots, n, 3))
+    acc[rng.uniform(size=(slots, n)) < 0.2] = np.nan         # missing accelerations: constant-velocity branch
+    z = mu[None, :, :3] + rng.normal(0, 0.05, (slots, n, 3))
+    Q = np.stack([spd3(rng, n) for _ in range(slots)]).reshape(slots, n, 9)
+    acc_r, z_r, Q_r = (torch.from_numpy(x).to("cuda", tdt).contiguous() for x in (acc, z, Q))
+    kind = int(rng.integers(0, 3))
+    dts = 10.0 ** rng.uniform(-3, -1.2, cycles)
+    models = rng.choice([-1, spe.MEAS_POS3, spe.MEAS_VEL3, spe.MEAS_ANGVEL3, 1, 2], cycles).astype(np.int32)
+    mixed = rng.integers(0, 9, (slots, n)).astype(np.int32)
+    mixed[rng.uniform(size=(slots, n)) < 0.2] = -1
+    mixed[mixed == 3] = 0                                      # (z is position-like: no axis-angle samples here)
+    m_r = torch.from_numpy(mixed).cuda().contiguous()
+    acc_cov = np.eye(3) * 10.0 ** rng.uniform(-4, -1)
+    a = spe.BatchPoseUKF(n, precision=prec); b = spe.BatchPoseUKF(n, precision=prec)
+    for e in (a, b):
+        e.initialize(mu, cov); e.set_acceleration(None, acc_cov)
+    st_or = np.zeros(n, dtype=np.uint32)
+    for c in range(cycles):
+        sl = (first + c) % slots
+        a.bind_acceleration_dev(acc_r[sl])
+        if kind == 0:
+            a.cycle_dev(float(dts[0]), int(abs(models[0]) % 9 if models[0] != 3 else 0), z_r[sl], Q_r[sl])
+        elif kind == 1:
+            if models[c] < 0:
+                a.predict(float(dts[c]))
+            else:
+                a.cycle_dev(float(dts[c]), int(models[c]), z_r[sl], Q_r[sl])
+        else:
+            a.cycle_dev(float(dts[0]), spe.MEAS_POS3, z_r[sl], Q_r[sl], meas_model_dev=m_r[sl])
+        st_or |= a.status()
+    if kind == 0:
+        b.cycle_multi_dev(cycles, float(dts[0]), int(abs(models[0]) % 9 if models[0] != 3 else 0), z_r, Q_r, slots, first, in_a_dev=acc_r)
+    elif kind == 1:
+        b.cycle_schedule_dev(dts, models, z_r, Q_r, slots, first, in_a_dev=acc_r)
+    else:
+        b.cycle_multi_mixed_dev(cycles, float(dts[0]), m_r, z_r, Q_r, slots, first, in_a_dev=acc_r)
+    m_a, c_a, _ = a.state(); m_b, c_b, _ = b.state()
+    compare(f"{['uniform', 'schedule', 'mixed'][kind]} cycles={cycles} slots={slots} first={first}", prec, m_b, c_b, b.status(),
+            m_a, c_a, st_or, fails, ctx)
+    a.close(); b.close()
+
+
 def run(count, seed):
     fails = []
     only = os.environ.get("FUZZ_ONLY")          # replay single scenarios: FUZZ_ONLY=2297,6101
@@ -199,6 +257,12 @@ def run(count, seed):
         (pose_scenario if k % 3 != 2 else orient_scenario)(rng, k, fails)
         if len(fails) > before:
             print("FAIL", fails[-1], flush=True)
+    if not only:
+        for k in range(count // 4):             # multi-cycle launches: their own streams, the numbering above stays as it was
+            before = len(fails)
+            multi_scenario(np.random.default_rng([seed, 10_000_000 + k]), k, fails)
+            if len(fails) > before:
+                print("FAIL", fails[-1], flush=True)
     print(f"fuzz_parity: {count} scenarios, {LAUNCHES[0]} launches compared, {len(fails)} failing (seed {seed}); largest error / tolerance: "
           f"fp64 {WORST[0]:.2e}, fp32 {WORST[1]:.2e}")
     return fails

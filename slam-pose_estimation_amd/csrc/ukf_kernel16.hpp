@@ -597,12 +597,25 @@ constexpr unsigned long long tri_cols(int first) {
 #endif
 template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W64 : UKFB_W32; }
 
+// Element idx of an array entered through a scalar base: the byte offset is formed in 32 bits, so that the load / store takes
+// the base as its scalar operand and the offset as its 32-bit vector operand (base[idx] would widen idx first and add in 64 bits)
+template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
+    using B = std::conditional_t<std::is_const_v<P>, const unsigned char, unsigned char>;
+    return reinterpret_cast<P*>(reinterpret_cast<B*>(base) + idx * uint32_t(sizeof(P)));
+}
+
 // MULTI (fused cycle only): KArgs::cyc_count consecutive cycles in one launch.  The filter is staged in LDS once, every
 // cycle reads its own input slot (requested one cycle ahead), the state goes back to HBM after the last cycle; the status
 // word is the OR over the cycles.  MULTI = false compiles the single-cycle kernel exactly as before (trip count 1).
-template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false>
+// INDIRECT (fused cycle only): work item i acts on filter fidx[i] (event rounds).  Direct launches -- everything else --
+// have the four filters of a workgroup side by side in every per-filter array: their addresses are a SCALAR base per
+// workgroup (64-bit arithmetic on the scalar unit) plus a small 32-bit lane offset, instead of a 64-bit multiply-add per
+// lane and stream (v_mad_u64_u32 / v_lshl_add_u64 issue at a quarter / half of the 32-bit rate: ~350 of the fp32
+// wavefront's 4 870 issue cycles went into them).
+template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false>
 __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
+    static_assert(!INDIRECT || (DO_PREDICT && DO_UPDATE && !MULTI), "indirect launches run the single fused cycle");
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
     constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
@@ -620,6 +633,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
 #else
 #define UKFB_HEADLINE_ACC(x) (x)
 #endif
+    if constexpr (!INDIRECT) __builtin_assume(a.fidx == nullptr);
     if constexpr (MULTI) {
         // multi-cycle launches are direct launches with one dt and one measurement model for every filter (checked by the
         // host): no per-filter timestamps, time steps, model ids, activity flags or filter index list to keep alive
@@ -629,10 +643,44 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     const int lane = threadIdx.x;
     // (not const: a multi-cycle launch re-derives everything that follows from the lane index in every cycle, see below)
     int g = lane >> 4, l = lane & 15;
-    int64_t f = int64_t(blockIdx.x) * FPW + g;
-    bool fvalid = f < a.n;
-    int64_t fi = fvalid ? f : (a.n - 1);                    // work item: index of the per-call inputs
-    int64_t fc = a.fidx ? int64_t(a.fidx[fi]) : fi;         // filter: index of the engine's state
+    // Indices of this row's work item (fi: per-call inputs) and filter (fc: engine state).  Direct launches: relative to the
+    // workgroup's first work item wg0 -- 0..3, 32 bits -- and every per-filter array below is entered at wg0 (scalar);
+    // indirect launches: absolute, 64 bits, the arrays as they are.
+    using IDX = std::conditional_t<INDIRECT, int64_t, uint32_t>;
+    const int64_t wg0 = INDIRECT ? int64_t(0) : int64_t(blockIdx.x) * FPW;
+    const int64_t n_here = a.n - wg0;                                   // work items from wg0 on (scalar)
+    const int n_wg = int(n_here < FPW ? n_here : int64_t(FPW));          // ... of this workgroup, direct launches
+    IDX f = INDIRECT ? IDX(int64_t(blockIdx.x) * FPW + g) : IDX(g);
+    bool fvalid = INDIRECT ? (int64_t(f) < a.n) : (g < n_wg);
+    IDX fi = fvalid ? f : (INDIRECT ? IDX(a.n - 1) : IDX(n_wg - 1));
+    IDX fc = INDIRECT ? IDX(a.fidx[fi]) : fi;
+    if constexpr (!INDIRECT) __builtin_assume(fi < 4u && fc < 4u);
+    const auto at_wg = [&](auto* p, int64_t stride) { return p ? p + wg0 * stride : p; };   // scalar pointer arithmetic
+    // element idx of a per-filter array (idx includes the row's fi / fc)
+    const auto at = [](auto* base, IDX idx) {
+        if constexpr (INDIRECT) return base + idx;
+        else return at32(base, idx);
+    };
+    // (the phases far from the prologue -- process noise, commit -- form their bases again from an opaque copy of the
+    // workgroup index: kept alive from here, fifteen pointers cost more registers than the arithmetic they save)
+    const auto wg0_again = [&]() {
+        unsigned b = blockIdx.x;
+        asm volatile("" : "+s"(b));
+        return INDIRECT ? int64_t(0) : int64_t(b) * FPW;
+    };
+    T* const mu_p = at_wg(a.mu, S);
+    T* const cov_p = at_wg(a.cov, PK);
+    uint32_t* const status_p = at_wg(a.status, 1);
+    const uint8_t* const init_p = at_wg(a.initialised, 1);
+    int64_t* const last_ts_p = at_wg(a.last_ts, 1);
+    const T* const in_a_p = at_wg(a.in_a, 3);
+    const T* const in_b_p = at_wg(a.in_b, 3);
+    const int64_t* const ts_p = at_wg(a.ts, 1);
+    const double* const dt_p = at_wg(a.dt, 1);
+    const int32_t* const meas_p = at_wg(a.meas, 1);
+    const uint8_t* const active_p = at_wg(a.active, 1);
+    const T* const z_p = at_wg(a.z, 3);
+    const T* const Q_p = at_wg(a.Q, 9);
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC;
     T* TAB = base + LY::TNL;
@@ -652,21 +700,25 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     // ---- prologue: EVERY per-filter stream is requested before the first dependent instruction, so the kernel
     // pays the HBM latency once.  Optional streams (null pointer) are read from a substitute address that is
     // always valid and the value is dropped by a select - a branch here would serialise the round trips.
-    const uint8_t init_b = a.initialised[fc];
+    const uint8_t init_b = *at(init_p, fc);
     int64_t last_l = 0, ts_l = 0;
     double dt_l = 0.0;
     if constexpr (DO_PREDICT) {
-        const int64_t* tsp = a.ts ? (a.ts + fi) : (a.last_ts + fc);
-        const double* dtp = a.dt ? (a.dt + fi) : reinterpret_cast<const double*>(a.last_ts + fc);
-        last_l = a.last_ts[fc];
+        // (optional streams: direct launches have fi == fc, the substitute is a scalar choice of the base)
+        const int64_t* tsp = INDIRECT ? (ts_p ? at(ts_p, fi) : at(static_cast<const int64_t*>(last_ts_p), fc))
+                                      : at(ts_p ? ts_p : static_cast<const int64_t*>(last_ts_p), fi);
+        const double* dtp = INDIRECT ? (dt_p ? at(dt_p, fi) : reinterpret_cast<const double*>(at(static_cast<const int64_t*>(last_ts_p), fc)))
+                                     : at(dt_p ? dt_p : reinterpret_cast<const double*>(last_ts_p), fi);
+        last_l = *at(last_ts_p, fc);
         ts_l = *tsp;
         dt_l = *dtp;
     }
     int32_t mid_l = 0;
     uint8_t act_b = 1;
     if constexpr (DO_UPDATE) {
-        const int32_t* mp = a.meas ? (a.meas + fi) : reinterpret_cast<const int32_t*>(a.status + fc);
-        const uint8_t* ap = a.active ? (a.active + fi) : (a.initialised + fc);
+        const int32_t* mp = INDIRECT ? (meas_p ? at(meas_p, fi) : reinterpret_cast<const int32_t*>(at(static_cast<const uint32_t*>(status_p), fc)))
+                                     : at(meas_p ? meas_p : reinterpret_cast<const int32_t*>(status_p), fi);
+        const uint8_t* ap = INDIRECT ? (active_p ? at(active_p, fi) : at(init_p, fc)) : at(active_p ? active_p : init_p, fi);
         mid_l = *mp;
         act_b = *ap;
     }
@@ -674,21 +726,21 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const int e = l + G * t;
-        cov_l[t] = a.cov[fc * PK + ((e < PK) ? e : (PK - 1))];
+        cov_l[t] = *at(static_cast<const T*>(cov_p), fc * PK + IDX((e < PK) ? e : (PK - 1)));
     }
-    const T mu_l = a.mu[fc * S + ((l < S) ? l : (S - 1))];
+    const T mu_l = *at(static_cast<const T*>(mu_p), fc * S + IDX((l < S) ? l : (S - 1)));
     ProcIn<T> pin;
     // per-call inputs of one input slot (single-cycle launches: slot 0 = the arrays themselves)
     const auto load_inputs = [&](int slot, T (&ia)[3], T (&ib)[3], T& zq, int32_t& mid_slot) {
-        const int64_t so = MULTI ? int64_t(slot) * a.cyc_items : 0;
+        const int64_t so = MULTI ? int64_t(slot) * a.cyc_items : 0;   // scalar: the slot's offset goes to the scalar base
         if constexpr (DO_UPDATE) {
-            const int32_t* mp = a.meas ? (a.meas + so + fi) : reinterpret_cast<const int32_t*>(a.status + fc);
+            const int32_t* mp = at(meas_p ? meas_p + so : reinterpret_cast<const int32_t*>(status_p), fi);   // (MULTI: direct, fi == fc)
             mid_slot = *mp;
         }
         if constexpr (DO_PREDICT) {
             // latched inputs: the engine always passes both arrays (its own or the bound ones)
-            const T* pa = a.in_a + ((MULTI && (a.cyc_in & 1)) ? so + fc : fc) * 3;
-            const T* pb = a.in_b + ((MULTI && (a.cyc_in & 2)) ? so + fc : fc) * 3;
+            const T* pa = at(in_a_p + ((MULTI && (a.cyc_in & 1)) ? so * 3 : 0), fc * 3);
+            const T* pb = at(in_b_p + ((MULTI && (a.cyc_in & 2)) ? so * 3 : 0), fc * 3);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 ia[k] = pa[k];
@@ -696,7 +748,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             }
         }
         if constexpr (DO_UPDATE) {
-            const T* zp = (l < 3) ? (a.z + (so + fi) * 3 + l) : (a.Q + (so + fi) * 9 + ((l < 12) ? (l - 3) : 0));
+            const T* zp = (l < 3) ? at(z_p + so * 3, fi * 3 + IDX(l)) : at(Q_p + so * 9, fi * 9 + IDX((l < 12) ? (l - 3) : 0));
             zq = *zp;
         }
     };
@@ -706,8 +758,8 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
         load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
     } else {
         if constexpr (DO_PREDICT) {
-            const T* pa = a.in_a + fc * 3;
-            const T* pb = a.in_b + fc * 3;
+            const T* pa = at(in_a_p, fc * 3);
+            const T* pb = at(in_b_p, fc * 3);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 pin.a[k] = pa[k];
@@ -715,7 +767,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             }
         }
         if constexpr (DO_UPDATE) {
-            const T* zp = (l < 3) ? (a.z + fi * 3 + l) : (a.Q + fi * 9 + ((l < 12) ? (l - 3) : 0));
+            const T* zp = (l < 3) ? at(z_p, fi * 3 + IDX(l)) : at(Q_p, fi * 9 + IDX((l < 12) ? (l - 3) : 0));
             zq_l = *zp;
         }
     }
@@ -743,9 +795,9 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
         asm volatile("" : "+v"(lane_c));
         g = lane_c >> 4;
         l = lane_c & 15;
-        f = int64_t(blockIdx.x) * FPW + g;
-        fvalid = f < a.n;
-        fi = fvalid ? f : (a.n - 1);
+        f = IDX(g);
+        fvalid = g < n_wg;
+        fi = fvalid ? f : IDX(n_wg - 1);
         fc = fi;   // (multi-cycle launches are direct: no filter index list)
         base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
         Lc = base + LY::LC;
@@ -840,7 +892,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     }
     wsync();
     if constexpr (DO_PREDICT) {
-        if (ts_store) a.last_ts[fc] = ts_l;   // after every load of the prologue has been issued
+        if (ts_store) *at(last_ts_p, fc) = ts_l;   // after every load of the prologue has been issued
     }
 
     bool p_commit = false, u_commit = false;
@@ -1119,8 +1171,9 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
 #pragma unroll
                     for (int k = 0; k < CT::WR_AFF_RD + AEL; ++k) ctw[k] = wrow[k];
                 }
-                const T* Rn = a.Rn + fc * a.Rn_stride;
-                const T* Ra = a.Racc + fc * a.Rn_stride;
+                const int64_t wgn = wg0_again() * a.Rn_stride;
+                const T* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
+                const T* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
                 // element imm behind byte offset off of the table p
                 const auto at_off = [](const T* p, uint32_t off, int imm) {
                     return reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p) + off)[imm];
@@ -1221,8 +1274,9 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 constexpr bool TILES_INSIDE = (M::MODEL == 0);   // Pose: every tile entry is a valid (row, column); Orient: rows 13, 14 are not
                 static_assert(!TILES_INSIDE || (10 + TR <= D && 3 + TC <= NL), "Pose tile table");
                 constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
-                const T* Rn = a.Rn + fc * a.Rn_stride;
-                const T* Ra = a.Racc + fc * a.Rn_stride;
+                const int64_t wgn = wg0_again() * a.Rn_stride;
+                const T* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
+                const T* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
                 const bool all_acc = NZ_EARLY && UKFB_HEADLINE_ACC(wave_all(pin.use_acc));
                 // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
                 // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
@@ -1792,15 +1846,23 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     UKFB_MARK("commit");
     // =========================================================================== commit
     const uint32_t st = st_all;
+    const int64_t wgc = wg0_again();
+    T* const cov_c = a.cov + wgc * PK;
+    T* const mu_c = a.mu + wgc * S;
+    uint32_t* const status_c = a.status + wgc;
+    // (the store offsets are the prologue's load offsets; formed again from an opaque copy of the row's index, or the
+    // compiler keeps all of them in registers across the whole kernel)
+    IDX fcc = fc;
+    if constexpr (!INDIRECT) asm volatile("" : "+v"(fcc));
     if (changed && fvalid) {
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const int e = l + G * t;
-            if (e < PK) a.cov[fc * PK + e] = PKS[e];
+            if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = PKS[e];
         }
-        if (l < S) a.mu[fc * S + l] = MUS[l];
+        if (l < S) *at(mu_c, fcc * S + IDX(l)) = MUS[l];
     }
-    if (fvalid && l == 0) a.status[fc] = a.status_accumulate ? (a.status[fc] | st) : st;
+    if (fvalid && l == 0) *at(status_c, fcc) = a.status_accumulate ? (*at(status_c, fcc) | st) : st;
 }
 
 }  // namespace ukfb

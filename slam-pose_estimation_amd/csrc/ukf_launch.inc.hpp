@@ -53,7 +53,9 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
     (void)hipMemsetAsync(dbuf, 0, need * 8, e->stream);
     args.stamps = dbuf;
     const dim3 gd((unsigned)grid), bd(64);
-    if (r.cycles > 0)
+    if (args.fidx)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, e->stream, args);
+    else if (r.cycles > 0)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, e->stream, args);
     else if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
@@ -109,7 +111,13 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
 #ifdef UKFB_STAMPS
     return launch_row16_stamped<T, M>(e, r, args, grid, lds);
 #endif
-    if (multi)
+    if (args.fidx) {   // indirect launch (event rounds): the fused cycle over a list of filters
+        if (multi || !(r.do_predict && r.do_update)) {
+            set_error("indirect launches run the single fused cycle", hipErrorInvalidValue);
+            return UKFB_ERR_INVALID_ARG;
+        }
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, e->stream, args);
+    } else if (multi)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, e->stream, args);
     else if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);

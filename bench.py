@@ -547,8 +547,12 @@ def run_rank(args):
             restore()
             ms = kernel_region(k_multi)
             eng.sync()
+            alg_cycle = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * (8 if prec == spe.F64 else 4) * per
             multi = {"cycles_per_launch": MULTI_CYCLES, "cycles": k_multi, "kernel_ms_per_cycle": ms,
                      "filter_cycles_per_s_per_gpu": per / (ms * 1e-3), "kernel": eng.last_launch_info()["kernel"],
+                     # the same algorithmic bytes per cycle as the headline's roofline (the state does not cross HBM between
+                     # the cycles of a launch, so the traffic actually moved is several times lower)
+                     "hbm_frac_algorithmic": alg_cycle / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "status_or": eng.status_summary(),
                      "note": "same start state and input ring as the timed region; kernel time (HIP events) of this rank"}
             cpl[0] = 1

@@ -53,6 +53,7 @@ def test_bench_line_has_the_contract_fields():
     m = d["multi_cycle"]                          # extra region: the same cycles as launches of 8 (never the headline value)
     assert m["cycles_per_launch"] == 8 and m["cycles"] % 8 == 0 and m["kernel_ms_per_cycle"] > 0 and m["status_or"] == 0
     assert "multicycle" in m["kernel"] and r["cycles_per_launch"] == 1 and "multicycle" not in r["kernel"]
+    assert m["parity"]["ok"] is True and m["parity"]["max_abs_cov"] <= 1e-9 and m["hbm_frac_algorithmic"] > 0
 
 
 def test_bench_other_workloads_run():

@@ -610,8 +610,8 @@ template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
 // INDIRECT (fused cycle only): work item i acts on filter fidx[i] (event rounds).  Direct launches -- everything else --
 // have the four filters of a workgroup side by side in every per-filter array: their addresses are a SCALAR base per
 // workgroup (64-bit arithmetic on the scalar unit) plus a small 32-bit lane offset, instead of a 64-bit multiply-add per
-// lane and stream (v_mad_u64_u32 / v_lshl_add_u64 issue at a quarter / half of the 32-bit rate: ~350 of the fp32
-// wavefront's 4 870 issue cycles went into them).
+// lane and stream (8 v_mad_u64_u32, 2 v_mul_lo_u32, 7 v_lshl_add_u64 per wavefront; 45 instructions fewer in all).  Measured:
+// +0.7 % fp64, nothing in fp32 -- the prologue is not where a wavefront's time goes.
 template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false>
 __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
@@ -635,8 +635,8 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
 #endif
     if constexpr (!INDIRECT) __builtin_assume(a.fidx == nullptr);
     if constexpr (MULTI) {
-        // multi-cycle launches are direct launches with one dt and one measurement model for every filter (checked by the
-        // host): no per-filter timestamps, time steps, model ids, activity flags or filter index list to keep alive
+        // multi-cycle launches are direct launches with one dt per cycle for every filter (checked by the host): no
+        // per-filter timestamps, time steps, activity flags or filter index list to keep alive
         __builtin_assume(a.fidx == nullptr); __builtin_assume(a.ts == nullptr); __builtin_assume(a.dt == nullptr);
         __builtin_assume(a.active == nullptr);   // (per-filter model ids are allowed: a ring like z and Q, negative = none)
     }

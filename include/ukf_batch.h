@@ -199,6 +199,13 @@ int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const
 int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
                    const void* Q_dev);
 
+/* One measurement covariance for the whole batch (the usual case: a sensor's covariance is a constant): Q9 is ONE 3x3
+ * (9 doubles / 9 engine-precision scalars on the device; leading m x m block used).  Same results as the per-filter
+ * forms with that matrix repeated; a quarter of the bytes across PCIe and no per-filter Q stream in the kernel. */
+int ukfb_update_uniform_q(ukfb_engine* e, int meas_model, const double* z, const double* Q9, const uint8_t* active);
+int ukfb_cycle_uniform_q(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q9);
+int ukfb_cycle_uniform_q_dev(ukfb_engine* e, double dt, int meas_model, const void* z_dev, const void* Q9_dev);
+
 /* `cycles` consecutive fused cycles in ONE launch (replay of buffered samples, catching up after a stall, fixed-rate
  * sensors whose samples are batched): predictionStep(dt) + integrateMeasurement(meas_model) `cycles` times for every
  * filter, exactly as `cycles` calls of ukfb_cycle_dev would -- same arithmetic, bit-identical state -- but the filter

@@ -1070,6 +1070,49 @@ int ukfb_cycle_multi(ukfb_engine* e, int cycles, double dt, int meas_model, cons
     return ukfb_cycle_multi_dev(e, cycles, dt, meas_model, cycles, 0, a_dev, b_dev, z_dev, Q_dev);
 }
 
+// ---- batch-uniform measurement covariance -------------------------------------------------------
+int ukfb_cycle_uniform_q_dev(ukfb_engine* e, double dt, int meas_model, const void* z_dev, const void* Q9_dev) {
+    if (!e || !z_dev || !Q9_dev) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.do_update = true;
+    r.dt_uniform = dt;
+    r.meas_uniform = meas_model;
+    r.z_dev = z_dev;
+    r.Q_dev = Q9_dev;
+    r.q_uniform = true;
+    return launch(e, r);
+}
+
+int ukfb_cycle_uniform_q(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q9) {
+    if (!e || !z || !Q9) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = upload(e, e->z_stage, 0, z, size_t(e->cap) * 3);
+    if (!rc) rc = upload(e, e->Q_stage, 0, Q9, 9);
+    if (rc) return rc;
+    return ukfb_cycle_uniform_q_dev(e, dt, meas_model, e->z_stage, e->Q_stage);
+}
+
+int ukfb_update_uniform_q(ukfb_engine* e, int meas_model, const double* z, const double* Q9, const uint8_t* active) {
+    if (!e || !z || !Q9) return UKFB_ERR_INVALID_ARG;
+    if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = upload(e, e->z_stage, 0, z, size_t(e->cap) * 3);
+    if (!rc) rc = upload(e, e->Q_stage, 0, Q9, 9);
+    if (!rc && active) rc = upload_raw(e, e->active_stage, active, size_t(e->cap));
+    if (rc) return rc;
+    ukfb::LaunchReq r;
+    r.do_update = true;
+    r.meas_uniform = meas_model;
+    r.z_dev = e->z_stage;
+    r.Q_dev = e->Q_stage;
+    r.q_uniform = true;
+    r.active_dev = active ? e->active_stage : nullptr;
+    return launch(e, r);
+}
+
 int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q) {
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");

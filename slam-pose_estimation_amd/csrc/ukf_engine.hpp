@@ -84,6 +84,7 @@ struct LaunchReq {
     const int32_t* meas_dev = nullptr;
     const void* z_dev = nullptr;
     const void* Q_dev = nullptr;
+    bool q_uniform = false;       // Q_dev holds ONE 3x3 (9 scalars) for the whole batch
     const uint8_t* active_dev = nullptr;
     // indirect launch over a list of filters (event rounds): n_items entries of filter_index_dev; -1: every filter
     const int32_t* filter_index_dev = nullptr;

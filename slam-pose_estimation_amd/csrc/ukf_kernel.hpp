@@ -70,7 +70,7 @@ template <class T> struct KArgs {
     int meas_uniform;
     const int32_t* meas;         // per filter, may be null
     const T* z;                  // [n][3]
-    const T* Q;                  // [n][9]
+    const T* Q;                  // [n][9]; q_uniform != 0: ONE 3x3 for every filter, [9]
     const uint8_t* active;       // [n], may be null
     // ---- ukfom constants
     T mean_tol;
@@ -84,6 +84,7 @@ template <class T> struct KArgs {
     int64_t cyc_items;
     // per-cycle schedule (cyc_sched != 0): time step and measurement model of cycle c instead of dt_uniform / meas_uniform;
     // a negative model = prediction only in that cycle.  Launch-wide scalars: the kernel reads them with scalar loads.
+    int q_uniform;               // the measurement covariance is batch-uniform: Q holds 9 scalars (single-cycle launches)
     int cyc_sched;
     int32_t cyc_model[UKFB_MAX_MULTI_CYCLES];
     double cyc_dt[UKFB_MAX_MULTI_CYCLES];
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(64, min_waves_per_simd<T>()) ukf_kernel(const 
         if (wave_any(do_u)) {
             {
                 const int zi = (l < 3) ? l : 0, qi = (l >= 3 && l < 12) ? (l - 3) : 0;
-                const T zv = a.z[fi * 3 + zi], qv = a.Q[fi * 9 + qi];
+                const T zv = a.z[fi * 3 + zi], qv = a.Q[(a.q_uniform ? 0 : fi * 9) + qi];
                 ZQ[(l < 12) ? l : (LY::DUM_OFF - LY::MISC_OFF - 44)] = (l < 3) ? zv : qv;
             }
             wsync();

@@ -680,7 +680,8 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     const int32_t* const meas_p = at_wg(a.meas, 1);
     const uint8_t* const active_p = at_wg(a.active, 1);
     const T* const z_p = at_wg(a.z, 3);
-    const T* const Q_p = at_wg(a.Q, 9);
+    const IDX q_stride = (!MULTI && a.q_uniform) ? 0 : 9;     // batch-uniform measurement covariance: every filter reads the same 9 scalars
+    const T* const Q_p = at_wg(a.Q, int64_t(q_stride));
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC;
     T* TAB = base + LY::TNL;
@@ -767,7 +768,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             }
         }
         if constexpr (DO_UPDATE) {
-            const T* zp = (l < 3) ? at(z_p, fi * 3 + IDX(l)) : at(Q_p, fi * 9 + IDX((l < 12) ? (l - 3) : 0));
+            const T* zp = (l < 3) ? at(z_p, fi * 3 + IDX(l)) : at(Q_p, fi * q_stride + IDX((l < 12) ? (l - 3) : 0));
             zq_l = *zp;
         }
     }

@@ -162,6 +162,7 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
     a.meas = r.meas_dev;
     a.z = static_cast<const T*>(r.z_dev);
     a.Q = static_cast<const T*>(r.Q_dev);
+    a.q_uniform = (r.q_uniform && r.cycles == 0) ? 1 : 0;
     a.active = r.active_dev;
     a.mean_tol = T(e->cfg.mean_tol);
     a.mean_max_it = e->cfg.mean_max_iter;

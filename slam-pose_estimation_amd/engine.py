@@ -43,7 +43,8 @@ EXPORTS = [
     "ukfb_orient_set_inputs", "ukfb_orient_bind_inputs_dev", "ukfb_orient_get_rotation_rate", "ukfb_predict",
     "ukfb_predict_dt", "ukfb_predict_timestamps", "ukfb_predict_dt_dev", "ukfb_predict_timestamps_dev",
     "ukfb_update", "ukfb_update_mixed", "ukfb_update_dev", "ukfb_cycle", "ukfb_cycle_dev", "ukfb_cycle_multi_dev", "ukfb_cycle_multi",
-    "ukfb_cycle_schedule_dev", "ukfb_cycle_multi_mixed_dev",
+    "ukfb_cycle_schedule_dev", "ukfb_cycle_multi_mixed_dev", "ukfb_update_uniform_q", "ukfb_cycle_uniform_q",
+    "ukfb_cycle_uniform_q_dev",
     "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
     "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
@@ -292,6 +293,21 @@ class BatchUKF:
     def cycle(self, dt: float, meas_model: int, z, Q):
         z = _f64(z, (self.capacity, 3)); Q = _f64(Q, (self.capacity, 3, 3))
         _chk(self._lib.ukfb_cycle(self._h, C.c_double(dt), C.c_int(meas_model), _pd(z), _pd(Q)), "ukfb_cycle")
+
+    def cycle_uniform_q(self, dt: float, meas_model: int, z, Q9):
+        """fused cycle with ONE 3x3 measurement covariance for the whole batch (host arrays)"""
+        z = _f64(z, (self.capacity, 3)); Q9 = _f64(Q9, (9,))
+        _chk(self._lib.ukfb_cycle_uniform_q(self._h, C.c_double(dt), C.c_int(meas_model), _pd(z), _pd(Q9)), "ukfb_cycle_uniform_q")
+
+    def cycle_uniform_q_dev(self, dt: float, meas_model: int, z_dev, Q9_dev):
+        _chk(self._lib.ukfb_cycle_uniform_q_dev(self._h, C.c_double(dt), C.c_int(meas_model), _devptr(z_dev), _devptr(Q9_dev)),
+             "ukfb_cycle_uniform_q_dev")
+
+    def update_uniform_q(self, meas_model: int, z, Q9, active=None):
+        z = _f64(z, (self.capacity, 3)); Q9 = _f64(Q9, (9,))
+        a = None if active is None else np.ascontiguousarray(active, dtype=np.uint8).reshape(self.capacity)
+        _chk(self._lib.ukfb_update_uniform_q(self._h, C.c_int(meas_model), _pd(z), _pd(Q9),
+                                             a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None), "ukfb_update_uniform_q")
 
     def cycle_dev(self, dt: float, meas_model_uniform: int, z_dev, Q_dev, meas_model_dev=None):
         _chk(self._lib.ukfb_cycle_dev(self._h, C.c_double(dt), C.c_int(meas_model_uniform), _devptr(meas_model_dev),

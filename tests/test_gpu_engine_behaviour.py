@@ -469,3 +469,35 @@ def test_event_stream_on_the_one_wavefront_per_filter_layout(spe, G):
     (mb, cb, _), sb, lb, ob, rb = out[1]
     assert ra == rb and oa == ob and (sa == sb).all() and (la == lb).all()
     assert max_abs(ma, mb) <= 1e-9 and max_abs(ca, cb) <= 1e-9
+
+
+@pytest.mark.parametrize("G", [16, 64])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_uniform_measurement_covariance_entry_points(spe, prec, G):
+    """ukfb_cycle_uniform_q / ukfb_update_uniform_q / ukfb_cycle_uniform_q_dev: ONE 3x3 for the batch = the per-filter forms
+    with that matrix repeated, bit for bit (Measurement.hpp:12: a measurement's cov is usually a sensor constant)."""
+    import torch
+    n = 203
+    s = spe.synth
+    mu, cov = s.pose_initial(n)
+    acc, z, _ = s.pose_cycle_inputs(n, 0, mu[:, :3])
+    Q1 = np.array([[0.004, 0.001, 0.0], [0.001, 0.003, -0.0005], [0.0, -0.0005, 0.002]])
+    Qn = np.broadcast_to(Q1, (n, 3, 3)).copy()
+
+    def engine():
+        e = spe.BatchPoseUKF(n, precision=prec, lanes_per_filter=G)
+        e.initialize(mu, cov); e.set_acceleration(acc, 0.01 * np.eye(3))
+        return e
+    a, b, c = engine(), engine(), engine()
+    a.cycle(0.01, spe.MEAS_POS3, z, Qn)
+    b.cycle_uniform_q(0.01, spe.MEAS_POS3, z, Q1)
+    tdt = torch.float64 if prec == 0 else torch.float32
+    z_t = torch.from_numpy(z).to("cuda", tdt); q_t = torch.from_numpy(Q1.reshape(9)).to("cuda", tdt); torch.cuda.synchronize()
+    c.cycle_uniform_q_dev(0.01, spe.MEAS_POS3, z_t, q_t); c.sync()
+    for e in (b, c):
+        assert np.array_equal(a.state()[0], e.state()[0]) and np.array_equal(a.state()[1], e.state()[1])
+    act = (np.arange(n) % 3 != 0).astype(np.uint8)
+    a.update(spe.MEAS_VEL_XY, z, Qn, active=act)
+    b.update_uniform_q(spe.MEAS_VEL_XY, z, Q1, active=act)
+    assert np.array_equal(a.state()[0], b.state()[0]) and np.array_equal(a.state()[1], b.state()[1])
+    assert (a.status() == b.status()).all()

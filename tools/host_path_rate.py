@@ -19,7 +19,9 @@ for lo in range(0, n, CH):
     zs.append(z); Qs.append(Q); accs.append(acc)
 z = np.concatenate(zs); Q = np.concatenate(Qs); acc = np.concatenate(accs)
 e.set_acceleration(acc, 0.01 * np.eye(3))
-for name, fn in (("host pointers (ukfb_cycle: uploads z, Q)", lambda: e.cycle(0.01, spe.MEAS_POS3, z, Q)),):
+Q1 = Q[0].copy()     # the synthetic Q is the same 3x3 for every filter
+for name, fn in (("host pointers (ukfb_cycle: uploads z, Q)", lambda: e.cycle(0.01, spe.MEAS_POS3, z, Q)),
+                 ("host pointers, one Q for the batch (ukfb_cycle_uniform_q: uploads z)", lambda: e.cycle_uniform_q(0.01, spe.MEAS_POS3, z, Q1))):
     fn(); e.sync()
     t0 = time.perf_counter(); k = 5
     for _ in range(k): fn()

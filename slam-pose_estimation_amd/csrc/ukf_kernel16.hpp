@@ -599,6 +599,19 @@ template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W6
 
 // Element idx of an array entered through a scalar base: the byte offset is formed in 32 bits, so that the load / store takes
 // the base as its scalar operand and the offset as its 32-bit vector operand (base[idx] would widen idx first and add in 64 bits)
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch).  With UKFB_XCD_REMAP the groups of four filters are
+// renumbered so that every XCD works through ONE contiguous eighth of the per-filter arrays (its own pages, its own L2
+// lines) instead of every eighth group of all of them.  Scalar arithmetic; a bijection for any grid size.  Same-box A/B:
+// fp32 +0.7 % (1 M filters), +0.9 % (131 072), config 4 +1.3 %; the fp64 configurations unchanged.
+#ifndef UKFB_XCD_REMAP
+#define UKFB_XCD_REMAP 1
+#endif
+UKFB_DEV unsigned group_of_block(unsigned b, unsigned nb) {
+    if constexpr (UKFB_XCD_REMAP == 0) return b;
+    const unsigned q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
     using B = std::conditional_t<std::is_const_v<P>, const unsigned char, unsigned char>;
     return reinterpret_cast<P*>(reinterpret_cast<B*>(base) + idx * uint32_t(sizeof(P)));
@@ -647,7 +660,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     // workgroup's first work item wg0 -- 0..3, 32 bits -- and every per-filter array below is entered at wg0 (scalar);
     // indirect launches: absolute, 64 bits, the arrays as they are.
     using IDX = std::conditional_t<INDIRECT, int64_t, uint32_t>;
-    const int64_t wg0 = INDIRECT ? int64_t(0) : int64_t(blockIdx.x) * FPW;
+    const int64_t wg0 = INDIRECT ? int64_t(0) : int64_t(group_of_block(blockIdx.x, gridDim.x)) * FPW;
     const int64_t n_here = a.n - wg0;                                   // work items from wg0 on (scalar)
     const int n_wg = int(n_here < FPW ? n_here : int64_t(FPW));          // ... of this workgroup, direct launches
     IDX f = INDIRECT ? IDX(int64_t(blockIdx.x) * FPW + g) : IDX(g);
@@ -666,7 +679,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     const auto wg0_again = [&]() {
         unsigned b = blockIdx.x;
         asm volatile("" : "+s"(b));
-        return INDIRECT ? int64_t(0) : int64_t(b) * FPW;
+        return INDIRECT ? int64_t(0) : int64_t(group_of_block(b, gridDim.x)) * FPW;
     };
     T* const mu_p = at_wg(a.mu, S);
     T* const cov_p = at_wg(a.cov, PK);

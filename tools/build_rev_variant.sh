@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds the engine of another git revision next to the product library, for same-box A/B timing with tools/ab.sh:
-#   tools/build_rev_variant.sh <name> <git-rev>  ->  slam-pose_estimation_amd/lib/ab/<name>.so
+#   [REV_FLAGS="..."] tools/build_rev_variant.sh <name> <git-rev>  ->  slam-pose_estimation_amd/lib/ab/<name>.so
+#   (REV_FLAGS: extra hipcc flags of that revision's Makefile; default = the current ones, empty for revisions before a2036cf)
 set -e
 name=$1; rev=$2
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -10,7 +11,7 @@ src=$wt/slam-pose_estimation_amd/csrc
 out=$root/slam-pose_estimation_amd/lib/ab; obj=$out/obj_$name; mkdir -p $obj
 pids=""
 for tu in ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -disable-machine-licm -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.log &
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize ${REV_FLAGS--mllvm -disable-machine-licm} -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.log &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done

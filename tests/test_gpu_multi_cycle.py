@@ -297,3 +297,43 @@ def test_mixed_model_multi_cycle(spe, oracle, prec, G):
         m_o, c_o, _ = oracle.pose_predict(m_o, c_o, R, cast(acc), acc_cov, 0.01)
         m_o, c_o, _ = oracle.pose_update(m_o, c_o, mods[c % slots], cast(z), cast(Q))
     assert max_abs(mb, m_o) <= TOL[prec] and max_abs(cb, c_o) <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_full_size_multi_cycle_equals_single_launches(spe, prec):
+    """The metric's 1 048 576 PoseWithVelocity filters: one launch of 6 cycles (ring of 4 input sets, starting at slot 3) and
+    the same 6 cycles as single launches leave the SAME bits in HBM -- compared on the device, every filter."""
+    import torch
+    from test_gpu_parity_configs import _dev_state
+    s = spe.synth
+    n, CH, slots, cycles, first = 1_048_576, 131_072, 4, 6, 3
+    tdt = _tdt(prec)
+    eng = spe.BatchPoseUKF(n, precision=prec)
+    acc_r = torch.empty((slots, n, 3), dtype=tdt, device="cuda")
+    z_r = torch.empty((slots, n, 3), dtype=tdt, device="cuda")
+    Q_r = torch.empty((slots, n, 9), dtype=tdt, device="cuda")
+    for lo in range(0, n, CH):
+        mu, cov = s.pose_initial(CH, first=lo)
+        eng.initialize(mu, cov, first=lo)
+        for k in range(slots):
+            acc, z, Q = s.pose_cycle_inputs(CH, k, mu[:, :3], first=lo)
+            acc_r[k, lo:lo + CH] = torch.from_numpy(acc).to("cuda", tdt)
+            z_r[k, lo:lo + CH] = torch.from_numpy(z).to("cuda", tdt)
+            Q_r[k, lo:lo + CH] = torch.from_numpy(Q.reshape(-1, 9)).to("cuda", tdt)
+    eng.set_acceleration(None, 0.01 * np.eye(3))
+    mu_v, cov_v = _dev_state(eng)
+    mu0, cov0 = mu_v.clone(), cov_v.clone()
+    for c in range(cycles):
+        k = (first + c) % slots
+        eng.bind_acceleration_dev(acc_r[k])
+        eng.cycle_dev(0.01, spe.MEAS_POS3, z_r[k], Q_r[k])
+    eng.sync()
+    assert eng.status_summary() == 0
+    mu1, cov1 = mu_v.clone(), cov_v.clone()
+    mu_v.copy_(mu0); cov_v.copy_(cov0)
+    torch.cuda.synchronize()
+    eng.cycle_multi_dev(cycles, 0.01, spe.MEAS_POS3, z_r, Q_r, slots, first, in_a_dev=acc_r)
+    eng.sync()
+    assert eng.status_summary() == 0 and "multicycle" in eng.last_launch_info()["kernel"]
+    assert torch.equal(mu_v, mu1) and torch.equal(cov_v, cov1)
+    assert not torch.equal(mu_v, mu0)

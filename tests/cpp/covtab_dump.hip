@@ -1,0 +1,30 @@
+// prints the compile-time lane tables of the covariance phase (ukf_kernel16.hpp: CovTab) as JSON; host code only
+#include <cstdio>
+#include "ukf_kernel16.hpp"
+template <class T, class M> static void dump(const char* name, bool last) {
+    using CT = ukfb::CovTab<T, M>;
+    using LY = ukfb::Layout16<T, M>;
+    constexpr auto t = CT::make();
+    std::printf("\"%s\": {\"SZ\": %d, \"D\": %d, \"NL\": %d, \"TR\": %d, \"TC\": %d, \"AEL\": %d, \"PKS\": %d, \"DUM\": %d, \"TNL\": %d, \"LAF\": %d, \"ST\": %d, \"TRIP\": %d, \"NRD\": %d, \"NWR\": %d,\n \"rd\": [",
+                name, CT::SZ, CT::D, CT::NL, CT::TR, CT::TC, CT::AEL, LY::PKS, LY::DUM, LY::TNL, LY::LAF, LY::ST, LY::TRIP, CT::NRD, CT::NWR);
+    for (int l = 0; l < 16; ++l) {
+        std::printf("%s[", l ? ", " : "");
+        for (int k = 0; k < CT::NRD; ++k) std::printf("%s%u", k ? ", " : "", t.rd[l][k]);
+        std::printf("]");
+    }
+    std::printf("],\n \"wr\": [");
+    for (int l = 0; l < 17; ++l) {
+        std::printf("%s[", l ? ", " : "");
+        for (int k = 0; k < CT::NWR; ++k) std::printf("%s%u", k ? ", " : "", t.wr[l][k]);
+        std::printf("]");
+    }
+    std::printf("]}%s\n", last ? "" : ",");
+}
+int main() {
+    std::printf("{\n");
+    dump<double, ukfb::PoseM<double>>("pose_f64", false);
+    dump<float, ukfb::PoseM<float>>("pose_f32", false);
+    dump<float, ukfb::OrientM<float>>("orient_f32", true);
+    std::printf("}\n");
+    return 0;
+}

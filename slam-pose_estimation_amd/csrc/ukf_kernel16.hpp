@@ -606,7 +606,7 @@ template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W6
 #ifndef UKFB_XCD_REMAP
 #define UKFB_XCD_REMAP 1
 #endif
-UKFB_DEV unsigned group_of_block(unsigned b, unsigned nb) {
+__host__ UKFB_DEV unsigned group_of_block(unsigned b, unsigned nb) {
     if constexpr (UKFB_XCD_REMAP == 0) return b;
     const unsigned q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
     return x * q + (x < r ? x : r) + i;

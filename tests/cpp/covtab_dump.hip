@@ -24,7 +24,15 @@ int main() {
     std::printf("{\n");
     dump<double, ukfb::PoseM<double>>("pose_f64", false);
     dump<float, ukfb::PoseM<float>>("pose_f32", false);
-    dump<float, ukfb::OrientM<float>>("orient_f32", true);
-    std::printf("}\n");
+    dump<float, ukfb::OrientM<float>>("orient_f32", false);
+    // XCD-aware numbering of the workgroups (group_of_block) for a few grid sizes
+    std::printf("\"group_of_block\": {");
+    const unsigned sizes[] = {1, 5, 8, 9, 13, 64, 1000, 16384};
+    for (unsigned k = 0; k < sizeof(sizes) / sizeof(sizes[0]); ++k) {
+        std::printf("%s\"%u\": [", k ? ", " : "", sizes[k]);
+        for (unsigned b = 0; b < sizes[k]; ++b) std::printf("%s%u", b ? ", " : "", ukfb::group_of_block(b, sizes[k]));
+        std::printf("]");
+    }
+    std::printf("}\n}\n");
     return 0;
 }

@@ -70,3 +70,15 @@ def test_every_entry_has_exactly_one_owner(tables, name):
         assert ws in (0, one_hi if SZ == 8 else 0x3F800000)
         if ws == 0 and stores:      # a cross lane owns its whole tile: all rows >= NL
             assert all((w // SZ - PKS) >= tri(NL, 0) for w in stores)
+
+
+def test_xcd_numbering_is_a_bijection_with_contiguous_eighths(tables):
+    """group_of_block: workgroup b runs on XCD b % 8; every XCD must get ONE contiguous run of groups, all groups exactly once"""
+    for nb_s, groups in tables["group_of_block"].items():
+        nb = int(nb_s)
+        assert sorted(groups) == list(range(nb))
+        for x in range(8):
+            mine = [groups[b] for b in range(x, nb, 8)]
+            assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True
+        starts = [groups[x] for x in range(min(8, nb))]
+        assert starts == sorted(starts)

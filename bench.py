@@ -309,10 +309,13 @@ def run_rank(args):
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # a bounded rendezvous: a rank that never arrives must fail the run, not hang it
+        limit = datetime.timedelta(seconds=300)
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=limit)
     dev = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
     coll_dev = dev if (args.backend == "nccl" and have_gpu) else torch.device("cpu")
 

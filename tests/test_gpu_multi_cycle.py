@@ -20,7 +20,9 @@ def _tdt(prec):
 def _rings(arrs, prec):
     """[slots][n][..] device rings from per-slot host arrays"""
     import torch
-    return torch.from_numpy(np.stack(arrs)).to("cuda", _tdt(prec)).contiguous()
+    t = torch.from_numpy(np.stack(arrs)).to("cuda", _tdt(prec)).contiguous()
+    torch.cuda.synchronize()       # the narrowing to fp32 runs on torch's stream; the engine launches on its own
+    return t
 
 
 @pytest.mark.parametrize("G", [16, 64])
@@ -321,8 +323,10 @@ def test_full_size_multi_cycle_equals_single_launches(spe, prec):
             z_r[k, lo:lo + CH] = torch.from_numpy(z).to("cuda", tdt)
             Q_r[k, lo:lo + CH] = torch.from_numpy(Q.reshape(-1, 9)).to("cuda", tdt)
     eng.set_acceleration(None, 0.01 * np.eye(3))
+    torch.cuda.synchronize()       # the rings were filled on torch's stream, the engine launches on its own
     mu_v, cov_v = _dev_state(eng)
     mu0, cov0 = mu_v.clone(), cov_v.clone()
+    torch.cuda.synchronize()
     for c in range(cycles):
         k = (first + c) % slots
         eng.bind_acceleration_dev(acc_r[k])
@@ -331,7 +335,7 @@ def test_full_size_multi_cycle_equals_single_launches(spe, prec):
     assert eng.status_summary() == 0
     mu1, cov1 = mu_v.clone(), cov_v.clone()
     mu_v.copy_(mu0); cov_v.copy_(cov0)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()       # (and the restored state before the engine's stream reads it)
     eng.cycle_multi_dev(cycles, 0.01, spe.MEAS_POS3, z_r, Q_r, slots, first, in_a_dev=acc_r)
     eng.sync()
     assert eng.status_summary() == 0 and "multicycle" in eng.last_launch_info()["kernel"]

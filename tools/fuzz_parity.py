@@ -217,6 +217,7 @@ def multi_scenario(rng, k, fails):
     mixed[rng.uniform(size=(slots, n)) < 0.2] = -1
     mixed[mixed == 3] = 0                                      # (z is position-like: no axis-angle samples here)
     m_r = torch.from_numpy(mixed).cuda().contiguous()
+    torch.cuda.synchronize()       # the rings were made on torch's stream; the engines launch on their own
     acc_cov = np.eye(3) * 10.0 ** rng.uniform(-4, -1)
     a = spe.BatchPoseUKF(n, precision=prec); b = spe.BatchPoseUKF(n, precision=prec)
     for e in (a, b):

@@ -548,11 +548,6 @@ def run_rank(args):
             k_multi = (max(args.steps, 64) + MULTI_CYCLES - 1) // MULTI_CYCLES * MULTI_CYCLES
             run_cycles(MULTI_CYCLES)      # first launch of this kernel (code load), untimed
             restore()
-            check = rank == 0 and not args.no_parity
-            if check:
-                sample_m = min(args.parity_sample, per)
-                m0_m, c0_m, _ = eng.state(0, sample_m)
-                k0_m = done[0]
             ms = kernel_region(k_multi)
             eng.sync()
             alg_cycle = (ALG_SCALARS_ORIENT if orient else ALG_SCALARS_POSE) * (8 if prec == spe.F64 else 4) * per
@@ -563,7 +558,14 @@ def run_rank(args):
                      "hbm_frac_algorithmic": alg_cycle / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "status_or": eng.status_summary(),
                      "note": "same start state and input ring as the timed region; kernel time (HIP events) of this rank"}
-            if check:   # the multi-cycle kernel's result against the oracle replay of the same cycles, from the same start state
+            if rank == 0 and not args.no_parity:
+                # one more launch of the multi-cycle kernel against the oracle replay of its cycles, from the state downloaded
+                # before it (the window of parity_recent: the fp32 engines drift from an fp64 replay over hundreds of cycles)
+                sample_m = min(args.parity_sample, per)
+                m0_m, c0_m, _ = eng.state(0, sample_m)
+                k0_m = done[0]
+                run_cycles(MULTI_CYCLES)
+                eng.sync()
                 multi["parity"] = parity_check(args, spe, eng, first, sample_m, done[0], orient, start=(m0_m, c0_m, k0_m))
             cpl[0] = 1
             fence()

@@ -120,3 +120,19 @@ def test_caller_text_written_against_the_reference_api_compiles(tmp_path, std):
                            os.path.join(ROOT, "tests", "cpp", "reference_caller_text.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_new_entry_points_reject_a_null_engine(spe):
+    """the multi-cycle and uniform-Q entry points return an error code for a NULL handle (no GPU needed, nothing is launched)"""
+    import ctypes as C
+    lib = spe.load_library()
+    null = C.c_void_p(None)
+    d9 = (C.c_double * 9)()
+    i1 = (C.c_int32 * 1)()
+    assert lib.ukfb_cycle_multi_dev(null, 1, C.c_double(0.01), 0, 1, 0, null, null, null, null) != 0
+    assert lib.ukfb_cycle_multi(null, 1, C.c_double(0.01), 0, null, null, d9, d9) != 0
+    assert lib.ukfb_cycle_multi_mixed_dev(null, 1, C.c_double(0.01), 1, 0, null, null, null, null, null) != 0
+    assert lib.ukfb_cycle_schedule_dev(null, 1, d9, i1, 1, 0, null, null, null, null) != 0
+    assert lib.ukfb_cycle_uniform_q(null, C.c_double(0.01), 0, d9, d9) != 0
+    assert lib.ukfb_cycle_uniform_q_dev(null, C.c_double(0.01), 0, null, null) != 0
+    assert lib.ukfb_update_uniform_q(null, 0, d9, d9, null) != 0

@@ -61,12 +61,27 @@ UKFB_DEV double fast_rsqrt(double x) {
     const double e = fma(-(x * r), r, 1.0);
     return fma(0.5 * r, e, r);
 }
-UKFB_DEV float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+// UKFB_F32_NEWTON (diagnostic / attribution switch, tests/drift_f32.py): 1 = one Newton step on the fp32 seeds as well
+#ifndef UKFB_F32_NEWTON
+#define UKFB_F32_NEWTON 0
+#endif
+UKFB_DEV float fast_rsqrt(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    if constexpr (UKFB_F32_NEWTON != 0) {
+        const float e = fmaf(-(x * r), r, 1.0f);
+        r = fmaf(0.5f * r, e, r);
+    }
+    return r;
+}
 UKFB_DEV double fast_rcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
-UKFB_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+UKFB_DEV float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    if constexpr (UKFB_F32_NEWTON != 0) r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
 
 // Near-minimax polynomials (Chebyshev fits computed with mpmath at 50 digits; max abs error quoted) for
 //   cos(sqrt(y)), sin(sqrt(y))/sqrt(y) on 0 <= y <= 0.62   and   atan(sqrt(u))/sqrt(u) on 0 <= u <= 0.07.
@@ -110,8 +125,21 @@ template <class T, int N> UKFB_DEV T horner(const T (&c)[N + 1], T x) {
         r = fma(r, x, c_[1]);                                           \
         r = fma(r, x, c_[0]);                                           \
     } while (0)
+// UKFB_F32_POLY_HI (diagnostic / attribution switch): 1 = the fp32 engines evaluate the fp64 fits (coefficients rounded to float)
+#ifndef UKFB_F32_POLY_HI
+#define UKFB_F32_POLY_HI 0
+#endif
+template <int N> UKFB_DEV float horner_from_double(const double (&c)[N + 1], float x) {
+    float r = float(c[N]);
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) r = fmaf(r, x, float(c[k]));
+    return r;
+}
 template <class T> UKFB_DEV void poly_cos_sinc(T y, T& c, T& s) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && UKFB_F32_POLY_HI != 0) {
+        c = horner_from_double<Poly<double>::NC>(Poly<double>::COS, y);
+        s = horner_from_double<Poly<double>::NS>(Poly<double>::SINC, y);
+    } else if constexpr (sizeof(T) == 4) {
         static_assert(Poly<float>::NC == 4 && Poly<float>::NS == 3, "literal Horner forms");
         UKFB_HORNER_LIT(Poly<float>::COS, 4, y, c);
         UKFB_HORNER_LIT(Poly<float>::SINC, 3, y, s);
@@ -121,7 +149,9 @@ template <class T> UKFB_DEV void poly_cos_sinc(T y, T& c, T& s) {
     }
 }
 template <class T> UKFB_DEV T poly_atan_ratio(T u) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && UKFB_F32_POLY_HI != 0) {
+        return horner_from_double<Poly<double>::NA>(Poly<double>::ATAN, u);
+    } else if constexpr (sizeof(T) == 4) {
         static_assert(Poly<float>::NA == 3, "literal Horner form");
         T r;
         UKFB_HORNER_LIT(Poly<float>::ATAN, 3, u, r);

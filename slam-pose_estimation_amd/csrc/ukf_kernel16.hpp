@@ -80,6 +80,11 @@ template <int C> UKFB_DEV void fmac_bcast(double& acc, double src, double m) {
 template <int C> UKFB_DEV float rcp_bcast(float v) {
     float r;
     asm volatile("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(C));
+    if constexpr (UKFB_F32_NEWTON != 0) {   // r += r (1 - v_C r): the residual reads lane C's pivot through DPP as well
+        float e = 1.0f;
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(e) : "v"(v), "v"(-r), "n"(C));
+        r = fmaf(e, r, r);
+    }
     return r;
 }
 // (fp64: the assembler accepts v_rcp_f64_dpp, the hardware does not broadcast for it -- every pivot came out wrong; the move stays)
@@ -214,6 +219,9 @@ template <class T> struct MT<OrientM<T>> {
     }
 };
 
+#ifndef UKFB_ISO_TOL_F32
+#define UKFB_ISO_TOL_F32 1e-4   // | |q|^2 - 1 | up to which an isotropic noise block is not rotated (fp32 engines)
+#endif
 #ifndef UKFB_F32_TRIM
 #define UKFB_F32_TRIM 1   // 0: the fp32 Pose slice as before round 2's last trim (424 floats, 21 workgroups per CU): -2.7 %
 #endif
@@ -935,7 +943,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 // (OrientationState kernels only: in the Pose kernels the two extra branches cost the acceleration-branch
                 // headline 0.6 % through code placement alone, same-box A/B)
                 if constexpr (M::MODEL != 0)
-                    noise_plain = a.noise_iso != 0 && wave_all(m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(1e-4)));
+                    noise_plain = a.noise_iso != 0 && wave_all(m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(UKFB_ISO_TOL_F32)));
                 if (!noise_plain && (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc)))) {
                     T q[4], rot[9];
                     M::orientation(mu_r, q);

@@ -1,0 +1,49 @@
+"""Long runs of the fp32 engines beside BOTH CPU oracles (round-2 verdict, item 1).
+
+north_star's fp32 tolerance is 1e-4 against the fp64 CPU algorithm.  The workloads bench.py times are not
+stationary (Pose: the position fix does not observe the orientation, whose variance grows by 0.001 rad^2 per cycle
+on the acceleration branch, PoseUKF.cpp:190-192; OrientationState: the latched specific force stays in the initial
+body frame while the gyro ring turns the filter, OrientationUKF.cpp:12-32), so ANY fp32 evaluation of the recursion
+leaves the fp64 one eventually.  What must hold, and what this test asserts over 600 cycles of 2048 filters:
+
+  1. attribution -- at every checkpoint the distance GPU fp32 <-> fp64 oracle is at most 2x the distance
+     float oracle <-> fp64 oracle (the same algorithm instantiated for float, oracle/ukf_oracle.hpp, prec=1):
+     the drift is fp32 arithmetic, not the kernel's reciprocal seeds, polynomial fits or noise shortcut
+     (profiles/r03_f32_drift_attribution.txt holds the diagnostic builds with each of them switched off);
+  2. horizon -- the fp32 engine stays within 1e-4 of the fp64 oracle up to HORIZON[workload] cycles
+     (profiles/r03_f32_drift_fine.txt: Pose covariance 9.0e-5 at cycle 500, 1.1e-4 at 525; OrientationState mean
+     7.7e-5 at cycle 150, 1.4e-4 at 175 -- where the float oracle is already at 4.8e-4);
+  3. the fp64 engine on the same run stays within 1e-9 for all 600 cycles.
+
+Models: /root/reference/src/pose_with_velocity/PoseUKF.cpp:88-97,180-196 and
+/root/reference/src/orientation_estimator/OrientationUKF.cpp:12-39,79-89.  PARITY UNPINNED w.r.t. real MTK."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import drift_f32  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL32, TOL64 = 1e-4, 1e-9
+HORIZON = {"pose": 500, "orient": 150}          # cycles of the bench workloads the fp32 engine holds 1e-4 for
+CHECKPOINTS = (1, 10, 50, 100, 150, 300, 500, 600)
+FLOOR = 2e-6   # below ~20 ulp of the largest state entries the ratio of two rounding-level distances means nothing
+
+
+@pytest.mark.parametrize("workload", ["pose", "orient"])
+def test_fp32_engine_beside_both_oracles(spe, oracle, workload):
+    rows = drift_f32.run(spe, oracle, workload, n=2048, cycles=600, checkpoints=CHECKPOINTS,
+                         threads=max(1, min(16, oracle.max_threads())), with_f64_engine=True)
+    print("\n" + drift_f32.fmt(rows))
+    assert [r["cycle"] for r in rows] == list(CHECKPOINTS)
+    for r in rows:
+        assert r["status"] == (0, 0, 0), r
+        for k in (0, 1):   # mean, covariance
+            g, o = r["gpu_o64"][k], r["o32_o64"][k]
+            assert g <= max(2.0 * o, FLOOR), (workload, r["cycle"], "mean" if k == 0 else "cov", g, o)
+            if r["cycle"] <= HORIZON[workload]:
+                assert g <= TOL32, (workload, r["cycle"], g)
+            assert r["gpu64_o64"][k] <= TOL64, (workload, r["cycle"], r["gpu64_o64"])

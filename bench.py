@@ -380,10 +380,10 @@ def run_rank(args):
     if orient:
         sy = spe.synth
         eng = spe.BatchOrientationUKF(per, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec,
-                                      device=dev.index, lanes_per_filter=args.lanes_per_filter)
+                                      device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private")
         eng.set_process_noise(sy.orient_process_noise())
     else:
-        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter)
+        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private")
     # input rings [N_RING][filters][..], contiguous (a multi-cycle launch addresses its slots inside them); *_d: the slots
     acc_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
     gyr_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev) if orient else None

@@ -89,24 +89,44 @@ enum {
 /* ---- configuration ---------------------------------------------------------------------- */
 typedef struct ukfb_config {
     double mean_tol;        /* ukfom meanSigmaPoints tolerance (1e-6)                        */
-    int32_t mean_max_iter;  /* ukfom meanSigmaPoints cap (engine default 100, ukfom 10000)   */
+    int32_t mean_max_iter;  /* ukfom meanSigmaPoints cap (10000, as ukfom)                   */
     double gate_chi2;       /* < 0: accept_any_mahalanobis_distance (PoseUKF.cpp:116)        */
     double min_time_delta;  /* UnscentedKalmanFilter.hpp:31  (1e-9)                          */
     double max_time_delta;  /* UnscentedKalmanFilter.hpp:32  (DBL_MAX)                       */
-    int32_t lanes_per_filter; /* 16, 32 or 64 lanes of a wavefront per filter; 0 = default   */
+    int32_t lanes_per_filter; /* 0 / 16 = the tuned layout (one DPP row per filter).  32 / 64 = one or two
+                               * filters per wavefront, the brief's literal decomposition kept as an ablation:
+                               * fp32 engines only in the shipped library (the fp64 instantiations need AGPRs and
+                               * are a diagnostic build option, `make GENERIC_F64=1`); ukfb_layout_supported tells */
+    int32_t bucket_models;  /* ukfb_cycle_dev with per-filter model ids (BASELINE config 5's mixed stream): 1 (default) = the
+                             * filters are first grouped on the device by what their update costs -- no sample / a linear
+                             * sub-state selection (PoseUKF.cpp:7-26,35-69) / the sigma-point path of
+                             * OrientationMeasurement (PoseUKF.cpp:28-33,133-138) -- so that every wavefront runs ONE of
+                             * the three paths; results are those of 0 (one launch in filter order) to rounding: a filter
+                             * never reads another filter's data.  Batches below 16 384 filters are never bucketed.   */
 } ukfb_config;
 
 int ukfb_default_config(ukfb_config* cfg);
+/* 1 if this build of the library can run `lanes_per_filter` lanes per filter at `precision`, else 0 */
+int ukfb_layout_supported(int precision, int lanes_per_filter);
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 /* Replaces `new MTK_UKF(initial_state, state_cov)` per filter (UnscentedKalmanFilter.hpp:42)
  * by one engine holding `capacity` filters on HIP device `device`.  `stream` is a hipStream_t
  * (NULL: the engine creates its own non-blocking stream). */
 int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream);
+/* The same, but `stream` is used exactly as given: NULL means the device's DEFAULT stream (hipStreamLegacy semantics),
+ * not "create one".  For callers whose buffers are produced on that stream (e.g. a framework's current stream):
+ * the "_dev" entry points then need no synchronisation between the producer and the engine. */
+int ukfb_create_on_stream(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream);
+/* Waits (bounded, see ukfb_sync) for the engine's stream, then frees everything.  If the stream never drains the
+ * engine is abandoned without freeing device memory and UKFB_ERR_HIP is returned: exit the process. */
 int ukfb_destroy(ukfb_engine* e);
 const char* ukfb_last_error(void);
 int ukfb_set_config(ukfb_engine* e, const ukfb_config* cfg);
 int ukfb_get_config(const ukfb_engine* e, ukfb_config* cfg);
+/* Waits for the engine's stream by polling, for at most UKFB_WAIT_TIMEOUT_S seconds (environment, default 120).  A
+ * wait that gives up returns UKFB_ERR_HIP ("timed out ...") and POISONS the engine: work of unknown state is still
+ * queued, every later call on it fails fast with UKFB_ERR_HIP, and the process is expected to exit non-zero. */
 int ukfb_sync(ukfb_engine* e);
 
 /* introspection: model, precision, capacity, S (stored scalars), D (DOF), packed cov length */

@@ -21,14 +21,26 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local bool g_wait_timed_out = false;   // the last bounded wait of this thread gave up (it wrote the error text itself)
 
 #define HIP_TRY(expr)                                      \
     do {                                                   \
         hipError_t _e = (expr);                            \
         if (_e != hipSuccess) {                            \
-            if (_e != hipErrorNotReady) ukfb::set_error(#expr, _e); /* NotReady: the bounded wait set the text */ \
+            if (!(_e == hipErrorNotReady && g_wait_timed_out)) ukfb::set_error(#expr, _e); \
+            g_wait_timed_out = false;                      \
             return UKFB_ERR_HIP;                           \
         }                                                  \
+    } while (0)
+
+// Waits for the engine's stream with the bounded polling wait (defined below).  A wait that gives up POISONS the engine:
+// work of unknown state is still queued, so every later call fails fast with UKFB_ERR_HIP, and ukfb_destroy neither waits
+// again nor frees device memory that a kernel in flight may still touch (the process is expected to exit non-zero).
+int engine_wait(ukfb_engine* e);
+#define ENGINE_SYNC(e)                                     \
+    do {                                                   \
+        const int _rc = engine_wait(e);                    \
+        if (_rc) return _rc;                               \
     } while (0)
 
 bool range_ok(const ukfb_engine* e, int64_t first, int64_t count) {
@@ -57,13 +69,13 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
     if (e->prec == UKFB_F64) {
         HIP_TRY(hipMemcpyAsync(static_cast<double*>(dst_dev) + elem_offset, src, n * sizeof(double),
                                hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
     } else if (n < 16384) {
         std::vector<float> tmp(n);
         convert(src, tmp.data(), n);
         HIP_TRY(hipMemcpyAsync(static_cast<float*>(dst_dev) + elem_offset, tmp.data(), n * sizeof(float),
                                hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
     } else {
         // fp32 engine, large array: the doubles cross PCIe as they are and are narrowed on the device (a
         // single-threaded host loop over 12 M values per cycle took ten times longer than the copy)
@@ -75,7 +87,7 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
         hipLaunchKernelGGL(narrow_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream,
                            static_cast<const double*>(e->cvt_dev), static_cast<float*>(dst_dev) + elem_offset, n);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
     }
     return UKFB_OK;
 }
@@ -83,7 +95,7 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
 // grow-only device scratch (see ukfb_engine::cvt_dev)
 int ensure_scratch(ukfb_engine* e, size_t bytes) {
     if (e->cvt_bytes >= bytes) return UKFB_OK;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    ENGINE_SYNC(e);
     if (e->cvt_dev) HIP_TRY(hipFree(e->cvt_dev));
     e->cvt_dev = nullptr;
     e->cvt_bytes = 0;
@@ -124,12 +136,12 @@ int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* ds
     if (e->prec == UKFB_F64) {
         HIP_TRY(hipMemcpyAsync(dst, static_cast<const double*>(src_dev) + elem_offset, n * sizeof(double),
                                hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
     } else if (n < 16384) {
         std::vector<float> tmp(n);
         HIP_TRY(hipMemcpyAsync(tmp.data(), static_cast<const float*>(src_dev) + elem_offset, n * sizeof(float),
                                hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
         for (size_t i = 0; i < n; ++i) dst[i] = double(tmp[i]);
     } else {   // fp32 engine, large array: widened on the device, the doubles cross PCIe as they are
         int rc = ensure_scratch(e, n * sizeof(double));
@@ -138,7 +150,7 @@ int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* ds
                            static_cast<const float*>(src_dev) + elem_offset, static_cast<double*>(e->cvt_dev), n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(dst, e->cvt_dev, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
     }
     return UKFB_OK;
 }
@@ -146,14 +158,14 @@ int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* ds
 template <class P> int upload_raw(ukfb_engine* e, P* dst_dev, const P* src, size_t n) {
     if (n == 0) return UKFB_OK;
     HIP_TRY(hipMemcpyAsync(dst_dev, src, n * sizeof(P), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    ENGINE_SYNC(e);
     return UKFB_OK;
 }
 
 template <class P> int download_raw(ukfb_engine* e, const P* src_dev, P* dst, size_t n) {
     if (n == 0) return UKFB_OK;
     HIP_TRY(hipMemcpyAsync(dst, src_dev, n * sizeof(P), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    ENGINE_SYNC(e);
     return UKFB_OK;
 }
 
@@ -163,6 +175,7 @@ int fill_scalar(ukfb_engine* e, void* dst_dev, size_t n, double value) {
 }
 
 int launch(ukfb_engine* e, const ukfb::LaunchReq& r) {
+    if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
     HIP_TRY(hipSetDevice(e->device));
     if (e->model == UKFB_MODEL_POSE)
         return e->prec == UKFB_F64 ? ukfb::launch_pose_f64(e, r) : ukfb::launch_pose_f32(e, r);
@@ -208,7 +221,7 @@ int rebuild_racc(ukfb_engine* e) {
     // both buffers persist for the life of the engine (Racc grows once, when the noise becomes per-filter)
     if (!e->Racc || e->Racc_mats < nmat) {
         if (e->Racc) {
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            ENGINE_SYNC(e);
             HIP_TRY(hipFree(e->Racc));
         }
         e->Racc = nullptr;
@@ -307,7 +320,7 @@ template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
     HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    ENGINE_SYNC(e);
     return UKFB_OK;
 }
 
@@ -362,6 +375,115 @@ __global__ void events_gather_kernel(const int64_t* filt, const int64_t* ts, con
     for (int c = 0; c < 9; ++c) Q_c[p * 9 + c] = T(Q[i * 9 + c]);
 }
 
+
+// ---- model-class buckets (ukfb_cycle_dev with per-filter model ids) ---------------------------------------
+// Class of a filter's update in this call: 0 = none (negative / invalid model id: prediction only), 1 = closed form (the eight
+// linear sub-state selections of PoseUKF), 2 = sigma-point path (PoseUKF OrientationMeasurement, OrientationUKF body velocity).
+// A stable three-way partition of the filter indices, two passes over the model ids: (1) per-block class counts, (2) every
+// block finds its offsets by summing the counts of the blocks before it (a few thousand values at most) and scatters.  The
+// classes follow each other from the most expensive to the cheapest, each
+// starts at a multiple of 4 (one wavefront = 4 filters); the list was pre-filled with -1, so the gaps read as padding.
+constexpr int BK_THREADS = 256, BK_PER_THREAD = 4, BK_BLOCK = BK_THREADS * BK_PER_THREAD;
+__device__ __forceinline__ int update_class(int engine_model, int mid) {
+    if (engine_model == UKFB_MODEL_POSE) return (mid < 0 || mid > 8) ? 0 : ((mid == 3) ? 2 : 1);
+    return (mid == 9) ? 2 : 0;
+}
+__global__ void __launch_bounds__(BK_THREADS) bucket_count_kernel(const int32_t* meas, int64_t n, int engine_model, uint32_t* counts,
+                                                                  int nblocks) {
+    using Reduce = hipcub::BlockReduce<uint32_t, BK_THREADS>;
+    __shared__ typename Reduce::TempStorage tmp;
+    const int64_t base = int64_t(blockIdx.x) * BK_BLOCK + int64_t(threadIdx.x) * BK_PER_THREAD;
+    uint32_t c1 = 0, c2 = 0, valid = 0;
+#pragma unroll
+    for (int j = 0; j < BK_PER_THREAD; ++j)
+        if (base + j < n) {
+            const int c = update_class(engine_model, meas[base + j]);
+            c1 += c == 1;
+            c2 += c == 2;
+            ++valid;
+        }
+    // (counts of at most 1024 each: two of them share a word)
+    const uint32_t packed = Reduce(tmp).Sum(c1 | (c2 << 16));
+    __syncthreads();
+    const uint32_t tot = Reduce(tmp).Sum(valid);
+    if (threadIdx.x == 0) {
+        const uint32_t n1 = packed & 0xFFFFu, n2 = packed >> 16;
+        counts[blockIdx.x] = tot - n1 - n2;
+        counts[nblocks + blockIdx.x] = n1;
+        counts[2 * nblocks + blockIdx.x] = n2;
+    }
+}
+__global__ void __launch_bounds__(BK_THREADS) bucket_scatter_kernel(const int32_t* meas, int64_t n, int engine_model,
+                                                                    const uint32_t* counts, int nblocks, int32_t* order) {
+    using Scan = hipcub::BlockScan<uint32_t, BK_THREADS>;
+    using Reduce = hipcub::BlockReduce<uint32_t, BK_THREADS>;
+    __shared__ typename Scan::TempStorage stmp;
+    __shared__ typename Reduce::TempStorage rtmp;
+    __shared__ uint32_t start[3];
+    // totals of every class and the counts of the blocks before this one
+    uint32_t before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += BK_THREADS)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t v = counts[c * nblocks + b];
+            total[c] += v;
+            before[c] += (b < int(blockIdx.x)) ? v : 0u;
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        total[c] = Reduce(rtmp).Sum(total[c]);
+        __syncthreads();
+        before[c] = Reduce(rtmp).Sum(before[c]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // the most expensive class first: the cheap wavefronts fill the tail of the launch
+        const uint32_t b1 = (total[2] + 3u) & ~3u, b0 = b1 + ((total[1] + 3u) & ~3u);
+        start[2] = before[2];
+        start[1] = b1 + before[1];
+        start[0] = b0 + before[0];
+    }
+    __syncthreads();
+    const int64_t base = int64_t(blockIdx.x) * BK_BLOCK + int64_t(threadIdx.x) * BK_PER_THREAD;
+    int cls[BK_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < BK_PER_THREAD; ++j) cls[j] = (base + j < n) ? update_class(engine_model, meas[base + j]) : -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < BK_PER_THREAD; ++j) mine += cls[j] == c;
+        uint32_t rank;
+        Scan(stmp).ExclusiveSum(mine, rank);
+        __syncthreads();
+        rank += start[c];
+#pragma unroll
+        for (int j = 0; j < BK_PER_THREAD; ++j)
+            if (cls[j] == c) order[rank++] = int32_t(base + j);
+    }
+}
+constexpr int64_t BUCKET_MIN_FILTERS = 16384;
+
+// fills e->bucket_idx for the model ids in meas_dev; *items = entries of the list that a launch must cover (an upper bound
+// known without reading anything back: every class is padded to a multiple of 4)
+int build_model_buckets(ukfb_engine* e, const int32_t* meas_dev, int64_t* items) {
+    const int64_t n = e->cap;
+    const int nblocks = int((n + BK_BLOCK - 1) / BK_BLOCK);
+    const size_t list = size_t(n) + 16;
+    if (!e->bucket_idx) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->bucket_idx), list * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->bucket_counts), size_t(3) * nblocks * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMemsetAsync(e->bucket_idx, 0xFF, list * sizeof(int32_t), e->stream));
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblocks), dim3(BK_THREADS), 0, e->stream, meas_dev, n, e->model, e->bucket_counts,
+                       nblocks);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblocks), dim3(BK_THREADS), 0, e->stream, meas_dev, n, e->model,
+                       static_cast<const uint32_t*>(e->bucket_counts), nblocks, e->bucket_idx);
+    HIP_TRY(hipGetLastError());
+    *items = (n + 3 + 3 + 3) / 4 * 4;   // sum of three counts each rounded up to 4 <= n + 9, itself rounded up to whole wavefronts
+    return UKFB_OK;
+}
+
 __global__ void or_reduce_kernel(const uint32_t* st, int64_t n, uint32_t* out) {
     uint32_t v = 0;
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
@@ -393,6 +515,7 @@ static double wait_timeout_seconds() {
 }
 template <class Query> static hipError_t wait_polling(Query&& query) {
     hipError_t r;
+    g_wait_timed_out = false;
     for (int spin = 0; spin < 20000; ++spin)
         if ((r = query()) != hipErrorNotReady) return r;
     const auto t0 = std::chrono::steady_clock::now();
@@ -400,6 +523,7 @@ template <class Query> static hipError_t wait_polling(Query&& query) {
         std::this_thread::sleep_for(std::chrono::microseconds(50));
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_timeout_seconds()) {
             g_last_error = "timed out waiting for the engine's stream (UKFB_WAIT_TIMEOUT_S)";
+            g_wait_timed_out = true;
             return hipErrorNotReady;
         }
     }
@@ -408,6 +532,21 @@ template <class Query> static hipError_t wait_polling(Query&& query) {
 static hipError_t wait_stream_polling(hipStream_t s) { return wait_polling([s] { return hipStreamQuery(s); }); }
 static hipError_t wait_event_polling(hipEvent_t ev) { return wait_polling([ev] { return hipEventQuery(ev); }); }
 
+namespace {
+int engine_wait(ukfb_engine* e) {
+    if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
+    const hipError_t r = wait_stream_polling(e->stream);
+    if (r == hipSuccess) return UKFB_OK;
+    if (r == hipErrorNotReady && g_wait_timed_out) {
+        e->poisoned = true;
+        g_wait_timed_out = false;
+    } else {
+        ukfb::set_error("waiting for the engine's stream", r);
+    }
+    return UKFB_ERR_HIP;
+}
+}  // namespace
+
 extern "C" {
 
 const char* ukfb_last_error(void) { return g_last_error.c_str(); }
@@ -415,17 +554,18 @@ const char* ukfb_last_error(void) { return g_last_error.c_str(); }
 int ukfb_default_config(ukfb_config* cfg) {
     if (!cfg) return UKFB_ERR_INVALID_ARG;
     cfg->mean_tol = 1e-6;
-    cfg->mean_max_iter = 100;
+    cfg->mean_max_iter = 10000;   // ukfom's cap; the loop is wave-uniform and leaves on convergence, the cap costs nothing
     cfg->gate_chi2 = -1.0;
     cfg->min_time_delta = 1.0e-9;
     cfg->max_time_delta = std::numeric_limits<double>::max();
     cfg->lanes_per_filter = 16;
+    cfg->bucket_models = 1;
     return UKFB_OK;
 }
 
-static int create_engine(ukfb_engine* e, int64_t capacity, void* stream) {
-    if (stream) {
-        e->stream = static_cast<hipStream_t>(stream);
+static int create_engine(ukfb_engine* e, int64_t capacity, void* stream, bool use_given_stream) {
+    if (stream || use_given_stream) {
+        e->stream = static_cast<hipStream_t>(stream);   // (NULL with use_given_stream: the device's default stream)
     } else {
         HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->own_stream = true;
@@ -464,11 +604,12 @@ static int create_engine(ukfb_engine* e, int64_t capacity, void* stream) {
     if (rc) return rc;
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    ENGINE_SYNC(e);
     return rebuild_racc(e);
 }
 
-int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream) {
+static int create_impl(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream,
+                       bool use_given_stream) {
     if (!out || capacity <= 0 || (model != UKFB_MODEL_POSE && model != UKFB_MODEL_ORIENT) ||
         (precision != UKFB_F64 && precision != UKFB_F32))
         return fail(UKFB_ERR_INVALID_ARG, "ukfb_create: bad argument");
@@ -491,7 +632,7 @@ int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, i
     e->PK = e->D * (e->D + 1) / 2;
     e->tsize = precision == UKFB_F64 ? 8 : 4;
     ukfb_default_config(&e->cfg);
-    const int rc = create_engine(e, capacity, stream);
+    const int rc = create_engine(e, capacity, stream, use_given_stream);
     if (rc) {   // release the stream, the events and every buffer allocated so far; keep the error text
         const std::string msg = g_last_error;
         ukfb_destroy(e);
@@ -502,13 +643,35 @@ int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, i
     return UKFB_OK;
 }
 
+int ukfb_create(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream) {
+    return create_impl(out, model, precision, capacity, device, stream, false);
+}
+
+int ukfb_create_on_stream(ukfb_engine** out, int model, int precision, int64_t capacity, int device, void* stream) {
+    return create_impl(out, model, precision, capacity, device, stream, true);
+}
+
+int ukfb_layout_supported(int precision, int lanes_per_filter) {
+    if (precision != UKFB_F64 && precision != UKFB_F32) return 0;
+    if (lanes_per_filter == 0 || lanes_per_filter == 16) return 1;
+    if (lanes_per_filter != 32 && lanes_per_filter != 64) return 0;
+    return (precision == UKFB_F32 || UKFB_GENERIC_F64 != 0) ? 1 : 0;
+}
+
 int ukfb_destroy(ukfb_engine* e) {
     if (!e) return UKFB_OK;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    // bounded: a kernel that never finishes must not pin the host in the teardown either.  A poisoned engine (this wait or
+    // an earlier one timed out) is abandoned as it is -- freeing memory under a kernel in flight would be worse than the leak
+    if (e->stream || !e->own_stream) (void)engine_wait(e);
+    if (e->poisoned) {
+        g_last_error = "ukfb_destroy: the engine's stream never drained; device memory left allocated, exit the process";
+        delete e;
+        return UKFB_ERR_HIP;
+    }
     void* bufs[] = {e->mu, e->cov, e->status, e->init, e->last_ts, e->Rn, e->Racc, e->acc_cov_dev, e->in_a, e->in_b, e->z_stage,
                     e->Q_stage, e->meas_stage, e->active_stage, e->dt_stage, e->ts_stage, e->reduce_word, e->ev_dev, e->cvt_dev,
-                    e->multi_dev};
+                    e->multi_dev, e->bucket_idx, e->bucket_counts};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -524,6 +687,8 @@ int ukfb_set_config(ukfb_engine* e, const ukfb_config* cfg) {
     if (c.lanes_per_filter == 0) c.lanes_per_filter = 16;
     if (c.lanes_per_filter != 16 && c.lanes_per_filter != 32 && c.lanes_per_filter != 64)
         return fail(UKFB_ERR_INVALID_ARG, "lanes_per_filter must be 16, 32 or 64");
+    if (!ukfb_layout_supported(e->prec, c.lanes_per_filter))
+        return fail(UKFB_ERR_INVALID_ARG, "lanes_per_filter 32 / 64 in fp64 is a diagnostic build option (make GENERIC_F64=1)");
     if (c.mean_max_iter < 1) return fail(UKFB_ERR_INVALID_ARG, "mean_max_iter must be >= 1");
     e->cfg = c;
     return UKFB_OK;
@@ -537,8 +702,7 @@ int ukfb_get_config(const ukfb_engine* e, ukfb_config* cfg) {
 
 int ukfb_sync(ukfb_engine* e) {
     if (!e) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(wait_stream_polling(e->stream));
-    return UKFB_OK;
+    return engine_wait(e);
 }
 
 int ukfb_describe(const ukfb_engine* e, int* model, int* precision, int64_t* capacity, int* S, int* D, int* PK) {
@@ -573,11 +737,11 @@ int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* 
             hipLaunchKernelGGL(pack_cov_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->cvt_dev),
                                static_cast<float*>(e->cov) + size_t(first + lo) * PK, m, D, PK);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(e->stream));   // the scratch is reused by the next chunk
+        ENGINE_SYNC(e);   // the scratch is reused by the next chunk
     }
     HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
     HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    ENGINE_SYNC(e);
     return UKFB_OK;
 }
 
@@ -605,7 +769,7 @@ int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, dou
                                    static_cast<const float*>(e->cov) + size_t(first + lo) * PK, static_cast<double*>(e->cvt_dev), m, D, PK);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(cov + size_t(lo) * D * D, e->cvt_dev, nfull * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            ENGINE_SYNC(e);
         }
     }
     if (initialised) {
@@ -683,7 +847,7 @@ int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t cou
     if (!e->Rn_per_filter) {
         void* big = nullptr;
         HIP_TRY(hipMalloc(&big, size_t(e->cap) * dd * e->tsize));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
         HIP_TRY(hipFree(e->Rn));
         e->Rn = big;
         e->Rn_per_filter = true;
@@ -924,6 +1088,21 @@ int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int3
     r.meas_dev = meas_model_dev;
     r.z_dev = z_dev;
     r.Q_dev = Q_dev;
+    if (meas_model_dev && e->cfg.bucket_models && e->cfg.lanes_per_filter == 16 && e->cap >= BUCKET_MIN_FILTERS &&
+        e->cap <= 0x7fffffff - 16) {
+        // Mixed stream: wavefronts of four neighbouring filters would each run the most expensive path any of the four
+        // needs.  Group the filters by the class of their update first (device side, nothing read back), then ONE indirect
+        // launch over the grouped list: every wavefront is class-uniform, the sigma-point branch of the update is taken by
+        // the wavefronts of that class only.
+        if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
+        HIP_TRY(hipSetDevice(e->device));
+        int64_t items = 0;
+        const int rc = build_model_buckets(e, meas_model_dev, &items);
+        if (rc) return rc;
+        r.filter_index_dev = e->bucket_idx;
+        r.inputs_by_filter = true;
+        r.n_items = items;
+    }
     return launch(e, r);
 }
 
@@ -1050,7 +1229,7 @@ int ukfb_cycle_multi(ukfb_engine* e, int cycles, double dt, int meas_model, cons
     const size_t nz = per * 3, nq = per * 9, na = in_a ? per * 3 : 0, nb = in_b ? per * 3 : 0;
     const size_t bytes = (nz + nq + na + nb) * e->tsize;
     if (e->multi_bytes < bytes) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        ENGINE_SYNC(e);
         if (e->multi_dev) HIP_TRY(hipFree(e->multi_dev));
         e->multi_dev = nullptr;
         e->multi_bytes = 0;
@@ -1311,7 +1490,7 @@ int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter,
     HIP_TRY(hipMemcpyAsync(d_z, z, 3 * ne * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d_q, Q, 9 * ne * sizeof(double), hipMemcpyHostToDevice, e->stream));
     rc = process_events_device<double>(e, n_events, d_f, d_t, d_m, d_z, d_q, c.used, status_or, rounds);
-    HIP_TRY(hipStreamSynchronize(e->stream));   // the caller's buffers are free again
+    ENGINE_SYNC(e);   // the caller's buffers are free again
     return rc;
 }
 
@@ -1355,8 +1534,17 @@ int ukfb_timer_begin(ukfb_engine* e) {
 
 int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms) {
     if (!e || !elapsed_ms) return UKFB_ERR_INVALID_ARG;
+    if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(wait_event_polling(e->ev1));
+    {
+        const hipError_t w = wait_event_polling(e->ev1);
+        if (w == hipErrorNotReady && g_wait_timed_out) {
+            e->poisoned = true;
+            g_wait_timed_out = false;
+            return UKFB_ERR_HIP;
+        }
+        HIP_TRY(w);
+    }
     HIP_TRY(hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
     return UKFB_OK;
 }

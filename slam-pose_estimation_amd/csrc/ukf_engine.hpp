@@ -14,6 +14,10 @@
 #define UKFB_MAX_MULTI_CYCLES 32   // cycles of one multi-cycle launch with a schedule (the host splits longer ones)
 #endif
 
+#ifndef UKFB_GENERIC_F64
+#define UKFB_GENERIC_F64 0   // 1: also build the fp64 one-wavefront-per-filter kernels (AGPR-backed, diagnostics only)
+#endif
+
 struct ukfb_engine {
     int model = 0, prec = 0, device = 0;
     int64_t cap = 0;
@@ -21,6 +25,7 @@ struct ukfb_engine {
     size_t tsize = 8;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool poisoned = false;   // a bounded wait gave up on this engine's stream: every later call fails fast (see ukfb_sync)
     ukfb_config cfg{};
 
     // per-filter device state
@@ -61,6 +66,10 @@ struct ukfb_engine {
     // ukfb_cycle_multi: device rings of the host samples of one call (grow-only)
     void* multi_dev = nullptr;
     size_t multi_bytes = 0;
+    // model-class buckets of ukfb_cycle_dev with per-filter model ids: filter list ordered by class, padded to whole
+    // wavefronts [cap + 16], and the per-block class counts [3][blocks]
+    int32_t* bucket_idx = nullptr;
+    uint32_t* bucket_counts = nullptr;
     // ukfb_process_events: device workspace (grow-only)
     void* ev_dev = nullptr;
     size_t ev_bytes = 0;
@@ -89,6 +98,7 @@ struct LaunchReq {
     // indirect launch over a list of filters (event rounds): n_items entries of filter_index_dev; -1: every filter
     const int32_t* filter_index_dev = nullptr;
     int64_t n_items = -1;
+    bool inputs_by_filter = false;   // the list also indexes the per-call inputs; negative entries are padding (buckets)
     bool status_accumulate = false;
     // multi-cycle launch (ukfb_cycle_multi_dev): cycles > 0 selects it; in_a_slots / in_b_slots replace the latched inputs
     int cycles = 0, first_slot = 0, slots = 1;

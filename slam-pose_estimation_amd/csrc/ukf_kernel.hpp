@@ -45,6 +45,9 @@ template <class T> struct KArgs {
     // z, Q) are indexed by i, the engine's per-filter state (everything else) by the filter.  Null: filter i.
     // A filter must not appear twice in one launch.
     const int32_t* fidx;
+    // != 0 (indirect launches of the tuned kernel, model-class buckets): the per-call inputs are per-FILTER arrays like the
+    // state (indexed by fidx[i], not by i), and a negative entry of fidx is padding: no filter, nothing loaded or stored for it
+    int fidx_inputs;
     int status_accumulate;       // != 0: OR the new status word into the stored one instead of replacing it
     int noise_iso;               // != 0: the two 3x3 diagonal noise blocks that the models rotate are multiples of the identity
                                  // (batch-uniform noise only) -- R s I R^T = s I, the rotation is skipped (ukf_kernel16.hpp)

@@ -675,6 +675,15 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     bool fvalid = INDIRECT ? (int64_t(f) < a.n) : (g < n_wg);
     IDX fi = fvalid ? f : (INDIRECT ? IDX(a.n - 1) : IDX(n_wg - 1));
     IDX fc = INDIRECT ? IDX(a.fidx[fi]) : fi;
+    if constexpr (INDIRECT) {
+        // model-class buckets (ukfb_cycle_dev with per-filter model ids): the list is ordered by class and padded to whole
+        // wavefronts with -1; z, Q and the model ids are the caller's per-filter arrays
+        if (a.fidx_inputs) {
+            fvalid = fvalid && (fc >= 0);
+            fc = (fc >= 0) ? fc : IDX(0);
+            fi = fc;
+        }
+    }
     if constexpr (!INDIRECT) __builtin_assume(fi < 4u && fc < 4u);
     const auto at_wg = [&](auto* p, int64_t stride) { return p ? p + wg0 * stride : p; };   // scalar pointer arithmetic
     // element idx of a per-filter array (idx includes the row's fi / fc)

@@ -137,6 +137,7 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
     KArgs<T> a{};
     a.n = r.n_items >= 0 ? r.n_items : e->cap;
     a.fidx = r.filter_index_dev;
+    a.fidx_inputs = (r.filter_index_dev && r.inputs_by_filter) ? 1 : 0;
     a.status_accumulate = r.status_accumulate ? 1 : 0;
     a.mu = static_cast<T*>(e->mu);
     a.cov = static_cast<T*>(e->cov);
@@ -183,11 +184,18 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
             }
         }
     }
-    switch (e->cfg.lanes_per_filter) {
-        case 64: return launch_g<T, M, 64>(e, r, a);
-        case 32: return launch_g<T, M, 32>(e, r, a);
-        default: return launch_row16<T, M>(e, r, a);
+    // The one-wavefront-per-filter layouts (ablation of the brief's literal decomposition) ship in fp32 only: their fp64
+    // instantiations need more than 256 VGPRs and the compiler parks the excess in AGPRs -- live-range-split copies of the
+    // kind DESIGN.md 4.5 distrusts with this toolchain.  -DUKFB_GENERIC_F64=1 (make GENERIC_F64=1) builds them for
+    // diagnostics; ukfb_set_config refuses the setting otherwise (ukfb_layout_supported tells).
+    if constexpr (sizeof(T) == 4 || UKFB_GENERIC_F64 != 0) {
+        switch (e->cfg.lanes_per_filter) {
+            case 64: return launch_g<T, M, 64>(e, r, a);
+            case 32: return launch_g<T, M, 32>(e, r, a);
+            default: break;
+        }
     }
+    return launch_row16<T, M>(e, r, a);
 }
 
 }  // namespace ukfb

@@ -35,7 +35,7 @@ ST_REJECTED_GATE = 1 << 9
 
 # every symbol include/ukf_batch.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "ukfb_default_config", "ukfb_create", "ukfb_destroy", "ukfb_last_error", "ukfb_set_config", "ukfb_get_config",
+    "ukfb_default_config", "ukfb_layout_supported", "ukfb_create", "ukfb_create_on_stream", "ukfb_destroy", "ukfb_last_error", "ukfb_set_config", "ukfb_get_config",
     "ukfb_sync", "ukfb_describe", "ukfb_initialize", "ukfb_get_state", "ukfb_get_status", "ukfb_get_status_summary",
     "ukfb_set_last_measurement_time", "ukfb_get_last_measurement_time", "ukfb_device_views",
     "ukfb_set_process_noise", "ukfb_set_process_noise_per_filter", "ukfb_get_process_noise",
@@ -54,7 +54,8 @@ BODY_STATE_SCALARS = 49
 
 class Config(C.Structure):
     _fields_ = [("mean_tol", C.c_double), ("mean_max_iter", C.c_int32), ("gate_chi2", C.c_double),
-                ("min_time_delta", C.c_double), ("max_time_delta", C.c_double), ("lanes_per_filter", C.c_int32)]
+                ("min_time_delta", C.c_double), ("max_time_delta", C.c_double), ("lanes_per_filter", C.c_int32),
+                ("bucket_models", C.c_int32)]
 
 
 class UkfbError(RuntimeError):
@@ -103,15 +104,44 @@ def _devptr(x):
     return C.c_void_p(int(x))
 
 
+def _torch_current_stream(device: int):
+    """hipStream_t of torch's current stream on `device` (0 = the default stream), or None when torch is not in use."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return None
+    try:
+        if not torch.cuda.is_available():
+            return None
+        return int(torch.cuda.current_stream(device).cuda_stream)
+    except Exception:
+        return None
+
+
+def layout_supported(precision: int, lanes_per_filter: int) -> bool:
+    return bool(load_library().ukfb_layout_supported(C.c_int(precision), C.c_int(lanes_per_filter)))
+
+
 class BatchUKF:
     """A batch of independent UKFs resident on one MI355X (opaque ukfb_engine handle)."""
 
     def __init__(self, model: int, precision: int, capacity: int, device: int = 0, stream=None,
                  lanes_per_filter: int = 0, **cfg):
+        """stream: None = torch's CURRENT stream on `device` when torch is imported and sees a GPU (tensors
+        the caller produces with torch and hands to the "_dev" entry points are then ordered with the engine's launches
+        without any synchronise), otherwise an engine-owned stream; "private" = always an engine-owned non-blocking
+        stream (bench.py: nothing else shares the timed stream); an int = that hipStream_t."""
         self._lib = load_library()
         self._h = C.c_void_p()
-        _chk(self._lib.ukfb_create(C.byref(self._h), C.c_int(model), C.c_int(precision), C.c_int64(capacity),
-                                   C.c_int(device), C.c_void_p(stream) if stream else None), "ukfb_create")
+        args = (C.byref(self._h), C.c_int(model), C.c_int(precision), C.c_int64(capacity), C.c_int(device))
+        if stream is None:
+            stream = _torch_current_stream(device)
+        if stream == "private" or stream is None:
+            self.stream_kind = "private"
+            _chk(self._lib.ukfb_create(*args, None), "ukfb_create")
+        else:
+            self.stream_kind = "given"
+            _chk(self._lib.ukfb_create_on_stream(*args, C.c_void_p(int(stream)) if int(stream) else None), "ukfb_create_on_stream")
         self.model, self.precision, self.capacity, self.device = model, precision, int(capacity), device
         self.S = 13 if model == MODEL_POSE else 14
         self.D = 12 if model == MODEL_POSE else 13

@@ -55,6 +55,13 @@ def test_default_config_matches_reference_defaults(spe):
     assert c.max_time_delta == np.finfo(np.float64).max   # UnscentedKalmanFilter.hpp:32
     assert c.gate_chi2 < 0                         # accept_any_mahalanobis_distance
     assert c.lanes_per_filter == 16
+    # ukfom's iteration cap, and the CPU oracle's (oracle/ukf_oracle.hpp:78): the engine must not give up earlier
+    from oracle import capi
+    assert c.mean_max_iter == 10000 == capi.default_config().mean_max_it
+    # layouts of this build: the tuned one in both precisions, the one-wavefront-per-filter ablation in fp32
+    assert lib.ukfb_layout_supported(spe.F64, 16) == 1 and lib.ukfb_layout_supported(spe.F32, 0) == 1
+    assert lib.ukfb_layout_supported(spe.F32, 32) == 1 and lib.ukfb_layout_supported(spe.F32, 64) == 1
+    assert lib.ukfb_layout_supported(spe.F64, 48) == 0 and lib.ukfb_layout_supported(7, 16) == 0
 
 
 def test_status_bits_agree_between_engine_binding_and_oracle(spe, onp):

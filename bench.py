@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
     ap.add_argument("--cpu-sample-seconds", type=float, default=6.0, help="target CPU time of each all-core sample")
     ap.add_argument("--parity-sample", type=int, default=4096)
+    ap.add_argument("--bucket-models", type=int, default=1, choices=[0, 1],
+                    help="pose-mixed: 1 (engine default) groups the filters by update class on the device before the launch, "
+                         "0 launches in filter order (ukfb_config.bucket_models; same-box A/B)")
     return ap.parse_args()
 
 
@@ -383,7 +386,8 @@ def run_rank(args):
                                       device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private")
         eng.set_process_noise(sy.orient_process_noise())
     else:
-        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private")
+        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private",
+                               bucket_models=args.bucket_models)
     # input rings [N_RING][filters][..], contiguous (a multi-cycle launch addresses its slots inside them); *_d: the slots
     acc_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
     gyr_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev) if orient else None

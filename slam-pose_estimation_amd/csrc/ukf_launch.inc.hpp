@@ -100,7 +100,7 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     const int64_t grid = (args.n + FPW - 1) / FPW;
     const int lds = FPW * lds_bytes_per_filter16<T, M>();
     const bool multi = r.cycles > 0;   // ukfb_cycle_multi_dev: fused cycles only (checked by the caller)
-    const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? "cycle" : "predict") : "update");
+    const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : "cycle") : "predict") : "update");
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
                      (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
     e->last_lds = lds;

@@ -273,7 +273,8 @@ def test_full_size_config5_mixed_fp64(spe, oracle):
         eng.bind_acceleration_dev(xs[0])
         eng.cycle_dev(0.01, spe.MEAS_POS3, xs[1], xs[2], meas_model_dev=xs[3])
         assert (eng.status_summary() & ~spe.ST_INACTIVE) == 0
-        assert eng.last_launch_info()["kernel"] == "ukf_kernel16<f64,pose,cycle>"
+        # (per-filter model ids on >= 16 384 filters: grouped by update class first, one indirect launch over the groups)
+        assert eng.last_launch_info()["kernel"] == "ukf_kernel16<f64,pose,cycle-bucketed>"
     ponly.set_acceleration(None, acc_cov); ponly.bind_acceleration_dev(a_t); ponly.predict(0.01)
     m_f, c_f, _ = full.state(); st = full.status()
     off = models_all < 0
@@ -305,3 +306,59 @@ def test_randomised_scenarios_against_the_oracle():
     fails = fz.run(120, 7)
     assert not fails, fails[:3]
     assert fz.LAUNCHES[0] > 400 and 0 < fz.WORST[0] < 1 and 0 < fz.WORST[1] < 1
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_model_buckets_equal_filter_order(spe, oracle, prec):
+    """ukfb_cycle_dev with per-filter model ids groups the filters by the class of their update (none / linear selection /
+    OrientationMeasurement's sigma-point path, PoseUKF.cpp:7-69,112-173) before ONE indirect launch, so that no wavefront
+    mixes classes.  A filter never reads another filter's data: the grouped launch must give what the launch in filter
+    order gives (bucket_models = 0) -- to rounding, the wave-uniform shortcuts may differ -- and what the oracle gives.
+    Sizes: ragged (not a multiple of 4 or of the 1024-filter partition blocks), and the degenerate mixes: one class only,
+    a class with fewer than four filters."""
+    import torch
+    s = spe.synth
+    tdt = torch.float64 if prec == 0 else torch.float32
+    tol = TOL[prec]
+    R = s.pose_default_process_noise()
+    acc_cov = 0.01 * np.eye(3)
+    rng = np.random.default_rng(5)
+    for n, mix in ((20_011, "nine"), (16_384, "all-so3"), (17_409, "none"), (16_390, "few")):
+        mu, cov = s.pose_initial(n)
+        acc, z, Q = s.pose_cycle_inputs(n, 0, mu[:, :3], random_q=True)
+        if mix == "nine":
+            models = s.pose_mixed_models(n, 0)
+        elif mix == "all-so3":
+            models = np.full(n, spe.MEAS_ORIENT_SO3, dtype=np.int32)
+        elif mix == "none":
+            models = np.full(n, -1, dtype=np.int32)
+        else:   # three filters in the sigma-point class, two without a sample, the rest position fixes
+            models = np.zeros(n, dtype=np.int32)
+            models[rng.choice(n, 3, replace=False)] = spe.MEAS_ORIENT_SO3
+            models[[7, n - 1]] = -1
+        zz = s.pose_measurement_for_model(mu, np.maximum(models, 0), z - mu[:, :3])
+        a_t = torch.from_numpy(acc).to("cuda", tdt)
+        z_t, Q_t = torch.from_numpy(zz).to("cuda", tdt), torch.from_numpy(Q.reshape(n, 9)).to("cuda", tdt)
+        m_t = torch.from_numpy(models).cuda()
+        torch.cuda.synchronize()
+        out = []
+        for buckets in (1, 0):
+            eng = spe.BatchPoseUKF(n, precision=prec, bucket_models=buckets)
+            eng.initialize(mu, cov)
+            eng.set_acceleration(None, acc_cov)
+            eng.bind_acceleration_dev(a_t)
+            eng.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t, meas_model_dev=m_t)
+            eng.sync()
+            assert ("bucketed" in eng.last_launch_info()["kernel"]) == (buckets == 1)
+            out.append((eng.state(), eng.status()))
+            eng.close()
+        (m_b, c_b, _), st_b = out[0]
+        (m_f, c_f, _), st_f = out[1]
+        assert (st_b == st_f).all()
+        assert max_abs(m_b, m_f) <= tol * 1e-3 and max_abs(c_b, c_f) <= tol * 1e-3
+        k = min(n, 4096)
+        cast = (lambda x: x) if prec == 0 else (lambda x: x.astype(np.float32).astype(np.float64))
+        m_o, c_o, s1 = oracle.pose_predict(mu[:k], cov[:k], R, cast(acc[:k]), acc_cov, 0.01, threads=8)
+        m_o, c_o, s2 = oracle.pose_update(m_o, c_o, models[:k], cast(zz[:k]), cast(Q[:k]), threads=8)
+        assert (s1 == 0).all() and (st_b[:k] == s2).all()
+        assert max_abs(m_b[:k], m_o) <= tol and max_abs(c_b[:k], c_o) <= tol

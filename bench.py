@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
     ap.add_argument("--cpu-sample-seconds", type=float, default=6.0, help="target CPU time of each all-core sample")
     ap.add_argument("--parity-sample", type=int, default=4096)
+    ap.add_argument("--split-streams", type=int, default=1, choices=[0, 1],
+                    help="1 (engine default): launches over 16 384 ... 262 143 filters run as two halves on two streams "
+                         "(ukfb_config.split_streams); 0: one launch on one stream (same-box A/B)")
     ap.add_argument("--bucket-models", type=int, default=1, choices=[0, 1],
                     help="pose-mixed: 1 (engine default) groups the filters by update class on the device before the launch, "
                          "0 launches in filter order (ukfb_config.bucket_models; same-box A/B)")
@@ -383,11 +386,12 @@ def run_rank(args):
     if orient:
         sy = spe.synth
         eng = spe.BatchOrientationUKF(per, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec,
-                                      device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private")
+                                      device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private",
+                                      split_streams=args.split_streams)
         eng.set_process_noise(sy.orient_process_noise())
     else:
         eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private",
-                               bucket_models=args.bucket_models)
+                               bucket_models=args.bucket_models, split_streams=args.split_streams)
     # input rings [N_RING][filters][..], contiguous (a multi-cycle launch addresses its slots inside them); *_d: the slots
     acc_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
     gyr_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev) if orient else None

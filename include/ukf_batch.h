@@ -25,8 +25,11 @@
  *  - "_dev" entry points take DEVICE pointers in the engine's compute precision (float or
  *    double) so that a caller whose inputs are already resident in HBM pays no PCIe copy.
  *    They are consumed on the engine's stream: buffers produced on another stream must be
- *    complete before the call (synchronise, or create the engine on the producer's stream),
- *    and must stay valid until ukfb_sync() or a later synchronising call returns.
+ *    complete before the call (synchronise, or create the engine on the producer's stream with
+ *    ukfb_create_on_stream), and must stay valid AND UNCHANGED until ukfb_sync() or a later
+ *    synchronising call returns -- an engine that owns its stream may run a launch as two halves
+ *    on two internal streams (ukfb_config.split_streams), so "the next call on the engine" is not
+ *    a point after which an input buffer may be rewritten; ukfb_sync() is.
  *  - per-filter failures never abort a call: they are reported in the per-filter status word
  *    (UKFB_ST_*), and a failing filter keeps the state it had before the call (the reference
  *    throws before mutating: UnscentedKalmanFilter.hpp:110-124).
@@ -103,6 +106,11 @@ typedef struct ukfb_config {
                              * OrientationMeasurement (PoseUKF.cpp:28-33,133-138) -- so that every wavefront runs ONE of
                              * the three paths; results are those of 0 (one launch in filter order) to rounding: a filter
                              * never reads another filter's data.  Batches below 16 384 filters are never bucketed.   */
+    int32_t split_streams;  /* 1 (default): an engine that owns its stream (ukfb_create with stream = NULL) runs a launch over
+                             * 16 384 ... 262 143 filters as two halves on two internal streams, so that the tail of one
+                             * launch overlaps the head of the next (small launches lose 4-8 % to their partly empty last
+                             * round of workgroups otherwise).  Bit-identical results; every other call joins the two streams
+                             * first.  Engines on a caller's stream never split: plain stream order holds for them.        */
 } ukfb_config;
 
 int ukfb_default_config(ukfb_config* cfg);

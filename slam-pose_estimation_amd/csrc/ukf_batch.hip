@@ -68,13 +68,13 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
     if (n == 0) return UKFB_OK;
     if (e->prec == UKFB_F64) {
         HIP_TRY(hipMemcpyAsync(static_cast<double*>(dst_dev) + elem_offset, src, n * sizeof(double),
-                               hipMemcpyHostToDevice, e->stream));
+                               hipMemcpyHostToDevice, ukfb::main_stream(e)));
         ENGINE_SYNC(e);
     } else if (n < 16384) {
         std::vector<float> tmp(n);
         convert(src, tmp.data(), n);
         HIP_TRY(hipMemcpyAsync(static_cast<float*>(dst_dev) + elem_offset, tmp.data(), n * sizeof(float),
-                               hipMemcpyHostToDevice, e->stream));
+                               hipMemcpyHostToDevice, ukfb::main_stream(e)));
         ENGINE_SYNC(e);
     } else {
         // fp32 engine, large array: the doubles cross PCIe as they are and are narrowed on the device (a
@@ -83,8 +83,8 @@ int upload(ukfb_engine* e, void* dst_dev, size_t elem_offset, const double* src,
             const int rc = ensure_scratch(e, n * sizeof(double));
             if (rc) return rc;
         }
-        HIP_TRY(hipMemcpyAsync(e->cvt_dev, src, n * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(narrow_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream,
+        HIP_TRY(hipMemcpyAsync(e->cvt_dev, src, n * sizeof(double), hipMemcpyHostToDevice, ukfb::main_stream(e)));
+        hipLaunchKernelGGL(narrow_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ukfb::main_stream(e),
                            static_cast<const double*>(e->cvt_dev), static_cast<float*>(dst_dev) + elem_offset, n);
         HIP_TRY(hipGetLastError());
         ENGINE_SYNC(e);
@@ -135,21 +135,21 @@ int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* ds
     if (n == 0) return UKFB_OK;
     if (e->prec == UKFB_F64) {
         HIP_TRY(hipMemcpyAsync(dst, static_cast<const double*>(src_dev) + elem_offset, n * sizeof(double),
-                               hipMemcpyDeviceToHost, e->stream));
+                               hipMemcpyDeviceToHost, ukfb::main_stream(e)));
         ENGINE_SYNC(e);
     } else if (n < 16384) {
         std::vector<float> tmp(n);
         HIP_TRY(hipMemcpyAsync(tmp.data(), static_cast<const float*>(src_dev) + elem_offset, n * sizeof(float),
-                               hipMemcpyDeviceToHost, e->stream));
+                               hipMemcpyDeviceToHost, ukfb::main_stream(e)));
         ENGINE_SYNC(e);
         for (size_t i = 0; i < n; ++i) dst[i] = double(tmp[i]);
     } else {   // fp32 engine, large array: widened on the device, the doubles cross PCIe as they are
         int rc = ensure_scratch(e, n * sizeof(double));
         if (rc) return rc;
-        hipLaunchKernelGGL(widen_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->stream,
+        hipLaunchKernelGGL(widen_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ukfb::main_stream(e),
                            static_cast<const float*>(src_dev) + elem_offset, static_cast<double*>(e->cvt_dev), n);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(dst, e->cvt_dev, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(dst, e->cvt_dev, n * sizeof(double), hipMemcpyDeviceToHost, ukfb::main_stream(e)));
         ENGINE_SYNC(e);
     }
     return UKFB_OK;
@@ -157,14 +157,14 @@ int download(ukfb_engine* e, const void* src_dev, size_t elem_offset, double* ds
 
 template <class P> int upload_raw(ukfb_engine* e, P* dst_dev, const P* src, size_t n) {
     if (n == 0) return UKFB_OK;
-    HIP_TRY(hipMemcpyAsync(dst_dev, src, n * sizeof(P), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(dst_dev, src, n * sizeof(P), hipMemcpyHostToDevice, ukfb::main_stream(e)));
     ENGINE_SYNC(e);
     return UKFB_OK;
 }
 
 template <class P> int download_raw(ukfb_engine* e, const P* src_dev, P* dst, size_t n) {
     if (n == 0) return UKFB_OK;
-    HIP_TRY(hipMemcpyAsync(dst, src_dev, n * sizeof(P), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, n * sizeof(P), hipMemcpyDeviceToHost, ukfb::main_stream(e)));
     ENGINE_SYNC(e);
     return UKFB_OK;
 }
@@ -235,10 +235,10 @@ int rebuild_racc(ukfb_engine* e) {
     const int64_t total = nmat * int64_t(dd);
     const int blocks = int((total + 255) / 256);
     if (e->prec == UKFB_F64)
-        hipLaunchKernelGGL(build_racc_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->Rn),
+        hipLaunchKernelGGL(build_racc_kernel<double>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), static_cast<const double*>(e->Rn),
                            static_cast<double*>(e->Racc), nmat, e->D, static_cast<const double*>(e->acc_cov_dev));
     else
-        hipLaunchKernelGGL(build_racc_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const float*>(e->Rn),
+        hipLaunchKernelGGL(build_racc_kernel<float>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), static_cast<const float*>(e->Rn),
                            static_cast<float*>(e->Racc), nmat, e->D, static_cast<const float*>(e->acc_cov_dev));
     HIP_TRY(hipGetLastError());
     return UKFB_OK;   // stream-ordered: the next launch on the engine's stream sees the new table
@@ -304,7 +304,7 @@ template <class T> int export_body_states(ukfb_engine* e, int64_t first, int64_t
     DevTmp dev;
     HIP_TRY(hipMalloc(&dev.p, size_t(count) * 49 * sizeof(T)));
     const int blocks = int((count * 49 + 255) / 256);
-    hipLaunchKernelGGL(export_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(e->mu),
+    hipLaunchKernelGGL(export_body_states_kernel<T>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), static_cast<const T*>(e->mu),
                        static_cast<const T*>(e->cov), first, count, static_cast<T*>(dev.p));
     HIP_TRY(hipGetLastError());
     return download(e, dev.p, 0, out, size_t(count) * 49);
@@ -315,11 +315,11 @@ template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t
     int rc = upload(e, dev.p, 0, in, size_t(count) * 49);
     if (rc) return rc;
     const int blocks = int((count * 91 + 255) / 256);
-    hipLaunchKernelGGL(import_body_states_kernel<T>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const T*>(dev.p), first,
+    hipLaunchKernelGGL(import_body_states_kernel<T>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), static_cast<const T*>(dev.p), first,
                        count, static_cast<T*>(e->mu), static_cast<T*>(e->cov));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
-    HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), ukfb::main_stream(e)));
     ENGINE_SYNC(e);
     return UKFB_OK;
 }
@@ -474,10 +474,10 @@ int build_model_buckets(ukfb_engine* e, const int32_t* meas_dev, int64_t* items)
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->bucket_idx), list * sizeof(int32_t)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->bucket_counts), size_t(3) * nblocks * sizeof(uint32_t)));
     }
-    HIP_TRY(hipMemsetAsync(e->bucket_idx, 0xFF, list * sizeof(int32_t), e->stream));
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblocks), dim3(BK_THREADS), 0, e->stream, meas_dev, n, e->model, e->bucket_counts,
+    HIP_TRY(hipMemsetAsync(e->bucket_idx, 0xFF, list * sizeof(int32_t), ukfb::main_stream(e)));
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model, e->bucket_counts,
                        nblocks);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblocks), dim3(BK_THREADS), 0, e->stream, meas_dev, n, e->model,
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model,
                        static_cast<const uint32_t*>(e->bucket_counts), nblocks, e->bucket_idx);
     HIP_TRY(hipGetLastError());
     *items = (n + 3 + 3 + 3) / 4 * 4;   // sum of three counts each rounded up to 4 <= n + 9, itself rounded up to whole wavefronts
@@ -535,7 +535,7 @@ static hipError_t wait_event_polling(hipEvent_t ev) { return wait_polling([ev] {
 namespace {
 int engine_wait(ukfb_engine* e) {
     if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
-    const hipError_t r = wait_stream_polling(e->stream);
+    const hipError_t r = wait_stream_polling(ukfb::main_stream(e));
     if (r == hipSuccess) return UKFB_OK;
     if (r == hipErrorNotReady && g_wait_timed_out) {
         e->poisoned = true;
@@ -560,6 +560,7 @@ int ukfb_default_config(ukfb_config* cfg) {
     cfg->max_time_delta = std::numeric_limits<double>::max();
     cfg->lanes_per_filter = 16;
     cfg->bucket_models = 1;
+    cfg->split_streams = 1;
     return UKFB_OK;
 }
 
@@ -569,6 +570,10 @@ static int create_engine(ukfb_engine* e, int64_t capacity, void* stream, bool us
     } else {
         HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->own_stream = true;
+        // the second stream of split launches (see ukf_launch.inc.hpp); a caller's stream keeps plain stream order
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
     }
     const size_t n = size_t(capacity), ts = e->tsize;
     HIP_TRY(hipMalloc(&e->mu, n * e->S * ts));
@@ -586,15 +591,15 @@ static int create_engine(ukfb_engine* e, int64_t capacity, void* stream, bool us
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->dt_stage), n * sizeof(double)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ts_stage), n * sizeof(int64_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->reduce_word), sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(e->mu, 0, n * e->S * ts, e->stream));
-    HIP_TRY(hipMemsetAsync(e->cov, 0, n * e->PK * ts, e->stream));
-    HIP_TRY(hipMemsetAsync(e->status, 0, n * sizeof(uint32_t), e->stream));
-    HIP_TRY(hipMemsetAsync(e->init, 0, n, e->stream));
-    HIP_TRY(hipMemsetAsync(e->last_ts, 0, n * sizeof(int64_t), e->stream));
-    HIP_TRY(hipMemsetAsync(e->Rn, 0, size_t(e->D) * e->D * ts, e->stream));  // UnscentedKalmanFilter.hpp:29
-    HIP_TRY(hipMemsetAsync(e->in_b, 0, n * 3 * ts, e->stream));
-    HIP_TRY(hipMemsetAsync(e->z_stage, 0, n * 3 * ts, e->stream));
-    HIP_TRY(hipMemsetAsync(e->Q_stage, 0, n * 9 * ts, e->stream));
+    HIP_TRY(hipMemsetAsync(e->mu, 0, n * e->S * ts, ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->cov, 0, n * e->PK * ts, ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->status, 0, n * sizeof(uint32_t), ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->init, 0, n, ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->last_ts, 0, n * sizeof(int64_t), ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->Rn, 0, size_t(e->D) * e->D * ts, ukfb::main_stream(e)));  // UnscentedKalmanFilter.hpp:29
+    HIP_TRY(hipMemsetAsync(e->in_b, 0, n * 3 * ts, ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->z_stage, 0, n * 3 * ts, ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->Q_stage, 0, n * 9 * ts, ukfb::main_stream(e)));
     e->Rn_host.assign(size_t(e->D) * e->D, 0.0);
     int rc;
     if (e->model == UKFB_MODEL_POSE)  // acceleration.mu = NaN until set (PoseUKF.cpp:109)
@@ -663,7 +668,7 @@ int ukfb_destroy(ukfb_engine* e) {
     (void)hipSetDevice(e->device);
     // bounded: a kernel that never finishes must not pin the host in the teardown either.  A poisoned engine (this wait or
     // an earlier one timed out) is abandoned as it is -- freeing memory under a kernel in flight would be worse than the leak
-    if (e->stream || !e->own_stream) (void)engine_wait(e);
+    (void)engine_wait(e);
     if (e->poisoned) {
         g_last_error = "ukfb_destroy: the engine's stream never drained; device memory left allocated, exit the process";
         delete e;
@@ -676,6 +681,9 @@ int ukfb_destroy(ukfb_engine* e) {
         if (b) (void)hipFree(b);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_a) (void)hipEventDestroy(e->ev_a);
+    if (e->ev_b) (void)hipEventDestroy(e->ev_b);
+    if (e->stream_b) (void)hipStreamDestroy(e->stream_b);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return UKFB_OK;
@@ -728,19 +736,19 @@ int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* 
         const size_t nfull = size_t(m) * D * D;
         rc = ensure_scratch(e, nfull * sizeof(double));
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(e->cvt_dev, cov + size_t(lo) * D * D, nfull * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->cvt_dev, cov + size_t(lo) * D * D, nfull * sizeof(double), hipMemcpyHostToDevice, ukfb::main_stream(e)));
         const unsigned blocks = unsigned((size_t(m) * PK + 255) / 256);
         if (e->prec == UKFB_F64)
-            hipLaunchKernelGGL(pack_cov_kernel<double>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->cvt_dev),
+            hipLaunchKernelGGL(pack_cov_kernel<double>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), static_cast<const double*>(e->cvt_dev),
                                static_cast<double*>(e->cov) + size_t(first + lo) * PK, m, D, PK);
         else
-            hipLaunchKernelGGL(pack_cov_kernel<float>, dim3(blocks), dim3(256), 0, e->stream, static_cast<const double*>(e->cvt_dev),
+            hipLaunchKernelGGL(pack_cov_kernel<float>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), static_cast<const double*>(e->cvt_dev),
                                static_cast<float*>(e->cov) + size_t(first + lo) * PK, m, D, PK);
         HIP_TRY(hipGetLastError());
         ENGINE_SYNC(e);   // the scratch is reused by the next chunk
     }
-    HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), e->stream));
-    HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->init + first, 1, size_t(count), ukfb::main_stream(e)));
+    HIP_TRY(hipMemsetAsync(e->last_ts + first, 0, size_t(count) * sizeof(int64_t), ukfb::main_stream(e)));
     ENGINE_SYNC(e);
     return UKFB_OK;
 }
@@ -762,13 +770,13 @@ int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, dou
             if (rc) return rc;
             const unsigned blocks = unsigned((nfull + 255) / 256);
             if (e->prec == UKFB_F64)
-                hipLaunchKernelGGL(unpack_cov_kernel<double>, dim3(blocks), dim3(256), 0, e->stream,
+                hipLaunchKernelGGL(unpack_cov_kernel<double>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e),
                                    static_cast<const double*>(e->cov) + size_t(first + lo) * PK, static_cast<double*>(e->cvt_dev), m, D, PK);
             else
-                hipLaunchKernelGGL(unpack_cov_kernel<float>, dim3(blocks), dim3(256), 0, e->stream,
+                hipLaunchKernelGGL(unpack_cov_kernel<float>, dim3(blocks), dim3(256), 0, ukfb::main_stream(e),
                                    static_cast<const float*>(e->cov) + size_t(first + lo) * PK, static_cast<double*>(e->cvt_dev), m, D, PK);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(cov + size_t(lo) * D * D, e->cvt_dev, nfull * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync(cov + size_t(lo) * D * D, e->cvt_dev, nfull * sizeof(double), hipMemcpyDeviceToHost, ukfb::main_stream(e)));
             ENGINE_SYNC(e);
         }
     }
@@ -788,9 +796,9 @@ int ukfb_get_status(ukfb_engine* e, int64_t first, int64_t count, uint32_t* stat
 int ukfb_get_status_summary(ukfb_engine* e, uint32_t* or_of_all) {
     if (!e || !or_of_all) return UKFB_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemsetAsync(e->reduce_word, 0, sizeof(uint32_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->reduce_word, 0, sizeof(uint32_t), ukfb::main_stream(e)));
     const int blocks = int(std::min<int64_t>((e->cap + 255) / 256, 1024));
-    hipLaunchKernelGGL(or_reduce_kernel, dim3(blocks), dim3(256), 0, e->stream, e->status, e->cap, e->reduce_word);
+    hipLaunchKernelGGL(or_reduce_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), e->status, e->cap, e->reduce_word);
     HIP_TRY(hipGetLastError());
     return download_raw(e, e->reduce_word, or_of_all, 1);
 }
@@ -1351,12 +1359,12 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     size_t tmp_sort_t = 0, tmp_sort_f = 0, tmp_scan = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort_t, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr),
                                                static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, 64,
-                                               e->stream));
+                                               ukfb::main_stream(e)));
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort_f, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
                                                static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n), 0, 32,
-                                               e->stream));
+                                               ukfb::main_stream(e)));
     HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
-                                              hipcub::Max(), int(n), e->stream));
+                                              hipcub::Max(), int(n), ukfb::main_stream(e)));
     const size_t tmp_bytes = std::max(tmp_sort_t, std::max(tmp_sort_f, tmp_scan));
     Carver c(static_cast<char*>(e->ev_dev) + ws_offset);
     const size_t ne = size_t(n);
@@ -1385,25 +1393,25 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     // ---- ordering, all on the device: by timestamp, then (stable) by filter = per-filter time order; the position of
     // a sample inside its filter's run is its round; then (stable) by round = round-major, filter-minor
     const int blocks = int((n + 255) / 256);
-    HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), e->stream));
-    hipLaunchKernelGGL(events_init_kernel, dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, n, e->cap, idx_a, key_t_a, flags);
+    HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), ukfb::main_stream(e)));
+    hipLaunchKernelGGL(events_init_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), d_f, d_t, n, e->cap, idx_a, key_t_a, flags);
     size_t tb = tmp_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_t_a, key_t_b, idx_a, idx_b, int(n), 0, 64, e->stream));
-    hipLaunchKernelGGL(events_filter_keys_kernel, dim3(blocks), dim3(256), 0, e->stream, d_f, idx_b, n, e->cap, key_f_a);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_t_a, key_t_b, idx_a, idx_b, int(n), 0, 64, ukfb::main_stream(e)));
+    hipLaunchKernelGGL(events_filter_keys_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), d_f, idx_b, n, e->cap, key_f_a);
     tb = tmp_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_f_a, key_f_b, idx_b, idx_c, int(n), 0, bits_f, e->stream));
-    hipLaunchKernelGGL(events_heads_kernel, dim3(blocks), dim3(256), 0, e->stream, key_f_b, n, head);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key_f_a, key_f_b, idx_b, idx_c, int(n), 0, bits_f, ukfb::main_stream(e)));
+    hipLaunchKernelGGL(events_heads_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), key_f_b, n, head);
     tb = tmp_bytes;
-    HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, start, hipcub::Max(), int(n), e->stream));
-    hipLaunchKernelGGL(events_rank_kernel, dim3(blocks), dim3(256), 0, e->stream, start, n, rank, flags);
+    HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, start, hipcub::Max(), int(n), ukfb::main_stream(e)));
+    hipLaunchKernelGGL(events_rank_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), start, n, rank, flags);
     tb = tmp_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, rank, rank_sorted, idx_c, idx_d, int(n), 0, 32, e->stream));
-    hipLaunchKernelGGL(events_round_offsets_kernel, dim3(blocks), dim3(256), 0, e->stream, rank_sorted, n, off);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, rank, rank_sorted, idx_c, idx_d, int(n), 0, 32, ukfb::main_stream(e)));
+    hipLaunchKernelGGL(events_round_offsets_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), rank_sorted, n, off);
     if (e->prec == UKFB_F64)
-        hipLaunchKernelGGL((events_gather_kernel<S, double>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z, d_q, idx_d,
+        hipLaunchKernelGGL((events_gather_kernel<S, double>), dim3(blocks), dim3(256), 0, ukfb::main_stream(e), d_f, d_t, d_m, d_z, d_q, idx_d,
                            n, fidx_c, ts_c, meas_c, reinterpret_cast<double*>(z_c), reinterpret_cast<double*>(Q_c));
     else
-        hipLaunchKernelGGL((events_gather_kernel<S, float>), dim3(blocks), dim3(256), 0, e->stream, d_f, d_t, d_m, d_z, d_q, idx_d,
+        hipLaunchKernelGGL((events_gather_kernel<S, float>), dim3(blocks), dim3(256), 0, ukfb::main_stream(e), d_f, d_t, d_m, d_z, d_q, idx_d,
                            n, fidx_c, ts_c, meas_c, reinterpret_cast<float*>(z_c), reinterpret_cast<float*>(Q_c));
     HIP_TRY(hipGetLastError());
     // ---- the one host read of the call: input validity, number of rounds and where each round starts (launch
@@ -1419,7 +1427,7 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
 
     // ---- one indirect fused launch per round over exactly the filters that have a sample in it: the cost of the
     // call follows the number of events, not rounds x capacity.  Status words accumulate (OR) across rounds.
-    HIP_TRY(hipMemsetAsync(e->status, 0, size_t(e->cap) * sizeof(uint32_t), e->stream));
+    HIP_TRY(hipMemsetAsync(e->status, 0, size_t(e->cap) * sizeof(uint32_t), ukfb::main_stream(e)));
     for (int64_t r = 0; r < nrounds; ++r) {
         const size_t o = hoff[size_t(r)], cnt = size_t(hoff[size_t(r) + 1]) - o;
         if (cnt == 0) continue;
@@ -1484,11 +1492,11 @@ int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter,
     int32_t* d_m = c.take<int32_t>(ne);
     double* d_z = c.take<double>(3 * ne);
     double* d_q = c.take<double>(9 * ne);
-    HIP_TRY(hipMemcpyAsync(d_f, filter, ne * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d_t, ts_us, ne * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d_m, meas_model, ne * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d_z, z, 3 * ne * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d_q, Q, 9 * ne * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_f, filter, ne * sizeof(int64_t), hipMemcpyHostToDevice, ukfb::main_stream(e)));
+    HIP_TRY(hipMemcpyAsync(d_t, ts_us, ne * sizeof(int64_t), hipMemcpyHostToDevice, ukfb::main_stream(e)));
+    HIP_TRY(hipMemcpyAsync(d_m, meas_model, ne * sizeof(int32_t), hipMemcpyHostToDevice, ukfb::main_stream(e)));
+    HIP_TRY(hipMemcpyAsync(d_z, z, 3 * ne * sizeof(double), hipMemcpyHostToDevice, ukfb::main_stream(e)));
+    HIP_TRY(hipMemcpyAsync(d_q, Q, 9 * ne * sizeof(double), hipMemcpyHostToDevice, ukfb::main_stream(e)));
     rc = process_events_device<double>(e, n_events, d_f, d_t, d_m, d_z, d_q, c.used, status_or, rounds);
     ENGINE_SYNC(e);   // the caller's buffers are free again
     return rc;
@@ -1528,14 +1536,14 @@ int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capa
 
 int ukfb_timer_begin(ukfb_engine* e) {
     if (!e) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    HIP_TRY(hipEventRecord(e->ev0, ukfb::main_stream(e)));
     return UKFB_OK;
 }
 
 int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms) {
     if (!e || !elapsed_ms) return UKFB_ERR_INVALID_ARG;
     if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
-    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventRecord(e->ev1, ukfb::main_stream(e)));
     {
         const hipError_t w = wait_event_polling(e->ev1);
         if (w == hipErrorNotReady && g_wait_timed_out) {

@@ -25,6 +25,12 @@ struct ukfb_engine {
     size_t tsize = 8;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // Small batches run a launch as two halves on two streams, so that the tail of one half overlaps the head of the next
+    // launch's other half (consecutive launches of one stream do not overlap).  stream_b carries the second half; ev_a / ev_b
+    // order it against everything else, which stays on `stream` (ukfb::main_stream joins first).  Engines that own their stream only.
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool split_pending = false;   // a second half is in flight on stream_b that `stream` has not waited for yet
     bool poisoned = false;   // a bounded wait gave up on this engine's stream: every later call fails fast (see ukfb_sync)
     ukfb_config cfg{};
 
@@ -114,5 +120,15 @@ int launch_orient_f64(ukfb_engine* e, const LaunchReq& r);
 int launch_orient_f32(ukfb_engine* e, const LaunchReq& r);
 
 void set_error(const char* what, hipError_t err);
+
+// The engine's stream for anything but a split launch: first makes it wait for the second half of the last split launch.
+inline hipStream_t main_stream(ukfb_engine* e) {
+    if (e->split_pending) {
+        (void)hipEventRecord(e->ev_b, e->stream_b);
+        (void)hipStreamWaitEvent(e->stream, e->ev_b, 0);
+        e->split_pending = false;
+    }
+    return e->stream;
+}
 
 }  // namespace ukfb

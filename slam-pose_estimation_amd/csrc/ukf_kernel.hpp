@@ -40,7 +40,8 @@ enum : uint32_t {
 #define UKFB_MAX_MULTI_CYCLES 32   // (also in ukf_engine.hpp, for the host side)
 #endif
 template <class T> struct KArgs {
-    int64_t n;                   // work items of this launch (= filters, or entries of fidx)
+    int64_t n;                   // work items of this launch (= filters, or entries of fidx): the launch covers [item0, n)
+    int64_t item0;               // direct launches of the tuned kernel: first work item (a batch run as two half launches)
     // Indirect launch (event streams): work item i acts on filter fidx[i]; the per-call inputs (ts, dt, meas, active,
     // z, Q) are indexed by i, the engine's per-filter state (everything else) by the filter.  Null: filter i.
     // A filter must not appear twice in one launch.

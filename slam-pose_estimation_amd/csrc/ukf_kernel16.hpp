@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     // workgroup's first work item wg0 -- 0..3, 32 bits -- and every per-filter array below is entered at wg0 (scalar);
     // indirect launches: absolute, 64 bits, the arrays as they are.
     using IDX = std::conditional_t<INDIRECT, int64_t, uint32_t>;
-    const int64_t wg0 = INDIRECT ? int64_t(0) : int64_t(group_of_block(blockIdx.x, gridDim.x)) * FPW;
+    const int64_t wg0 = INDIRECT ? int64_t(0) : a.item0 + int64_t(group_of_block(blockIdx.x, gridDim.x)) * FPW;
     const int64_t n_here = a.n - wg0;                                   // work items from wg0 on (scalar)
     const int n_wg = int(n_here < FPW ? n_here : int64_t(FPW));          // ... of this workgroup, direct launches
     IDX f = INDIRECT ? IDX(int64_t(blockIdx.x) * FPW + g) : IDX(g);
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
     const auto wg0_again = [&]() {
         unsigned b = blockIdx.x;
         asm volatile("" : "+s"(b));
-        return INDIRECT ? int64_t(0) : int64_t(group_of_block(b, gridDim.x)) * FPW;
+        return INDIRECT ? int64_t(0) : a.item0 + int64_t(group_of_block(b, gridDim.x)) * FPW;
     };
     T* const mu_p = at_wg(a.mu, S);
     T* const cov_p = at_wg(a.cov, PK);

@@ -24,11 +24,11 @@ template <class T, class M, int G> static int launch_g(ukfb_engine* e, const Lau
     if (grid == 0) return UKFB_OK;
     const dim3 gd((unsigned)grid), bd(64);
     if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel<T, M, G, true, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel<T, M, G, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel<T, M, G, true, false>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel<T, M, G, true, false>), gd, bd, lds, main_stream(e), args);
     else
-        hipLaunchKernelGGL((ukf_kernel<T, M, G, false, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel<T, M, G, false, true>), gd, bd, lds, main_stream(e), args);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("kernel launch", err);
@@ -50,20 +50,20 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
         if (hipMalloc(reinterpret_cast<void**>(&dbuf), need * 8) != hipSuccess) return UKFB_ERR_HIP;
         dcap = need;
     }
-    (void)hipMemsetAsync(dbuf, 0, need * 8, e->stream);
+    (void)hipMemsetAsync(dbuf, 0, need * 8, main_stream(e));
     args.stamps = dbuf;
     const dim3 gd((unsigned)grid), bd(64);
     if (args.fidx)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
     else if (r.cycles > 0)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, main_stream(e), args);
     else
-        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, e->stream, args);
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return UKFB_ERR_HIP;
+        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, main_stream(e), args);
+    if (hipStreamSynchronize(main_stream(e)) != hipSuccess) return UKFB_ERR_HIP;
     const char* path = getenv("UKFB_STAMP_OUT");
     if (!path) return UKFB_OK;
     std::vector<unsigned long long> h(need);
@@ -94,6 +94,17 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
 }
 #endif
 
+constexpr int64_t SPLIT_MIN_FILTERS = 16384;
+// (UKFB_SPLIT_MAX in the environment moves the upper bound: measurements only)
+static int64_t split_max_filters() {
+    static const int64_t v = [] {
+        const char* s = std::getenv("UKFB_SPLIT_MAX");
+        const long long x = s ? std::atoll(s) : 0;
+        return int64_t(x > 0 ? x : 262144);
+    }();
+    return v;
+}
+
 // tuned kernel: one DPP row per filter (ukf_kernel16.hpp)
 template <class T, class M> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
     constexpr int FPW = 4;
@@ -111,20 +122,48 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
 #ifdef UKFB_STAMPS
     return launch_row16_stamped<T, M>(e, r, args, grid, lds);
 #endif
+    // Two half launches on two streams (engines that own their stream, direct launches of SPLIT_MIN <= n < SPLIT_MAX filters):
+    // launch k + 1's first half follows launch k's first half on `stream`, its second half follows launch k's second half on
+    // stream_b -- the tail of one half (a partly empty last round of workgroups) overlaps the head of the other stream's next
+    // kernel.  Filters are independent, the halves touch disjoint filters: results are bit-identical.
+    if (!args.fidx && e->stream_b && e->cfg.split_streams && args.n >= SPLIT_MIN_FILTERS && args.n < split_max_filters()) {
+        KArgs<T> h1 = args, h2 = args;
+        h1.n = (args.n / 2 + FPW - 1) / FPW * FPW;
+        h2.item0 = h1.n;
+        const dim3 g1((unsigned)(h1.n / FPW)), g2((unsigned)((args.n - h1.n + FPW - 1) / FPW));
+        hipStream_t sa = e->stream, sb = e->stream_b;    // (raw: a pending second half is NOT joined, that is the point)
+        (void)hipEventRecord(e->ev_a, sa);               // stream_b sees everything enqueued on `stream` so far
+        (void)hipStreamWaitEvent(sb, e->ev_a, 0);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, g1, bd, lds, sa, h1);
+            hipLaunchKernelGGL(kern, g2, bd, lds, sb, h2);
+        };
+        if (multi) go(ukf_kernel16<T, M, true, true, true>);
+        else if (r.do_predict && r.do_update) go(ukf_kernel16<T, M, true, true>);
+        else if (r.do_predict) go(ukf_kernel16<T, M, true, false>);
+        else go(ukf_kernel16<T, M, false, true>);
+        e->split_pending = true;
+        const hipError_t serr = hipGetLastError();
+        if (serr != hipSuccess) {
+            set_error("kernel launch (split)", serr);
+            return UKFB_ERR_HIP;
+        }
+        return UKFB_OK;
+    }
     if (args.fidx) {   // indirect launch (event rounds): the fused cycle over a list of filters
         if (multi || !(r.do_predict && r.do_update)) {
             set_error("indirect launches run the single fused cycle", hipErrorInvalidValue);
             return UKFB_ERR_INVALID_ARG;
         }
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
     } else if (multi)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, main_stream(e), args);
     else
-        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, e->stream, args);
+        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, main_stream(e), args);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("kernel launch", err);

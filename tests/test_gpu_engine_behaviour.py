@@ -561,3 +561,41 @@ def test_mean_iteration_cap_is_ukfoms(spe, oracle):
         e2.close()
     assert len(seen) > 1      # the caps straddle the trip counts of these filters
     eng.close()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_split_launches_are_bit_identical(spe, prec):
+    """An engine that owns its stream runs a launch over 16 384 ... 262 143 filters as two halves on two streams
+    (ukfb_config.split_streams, include/ukf_batch.h).  Filters are independent (UnscentedKalmanFilter.hpp:150) and the halves
+    touch disjoint filters, so every entry point must give the bits of the single launch: fused cycles back to back without a
+    synchronise in between, a prediction, an update, a multi-cycle launch, and the calls that join the two streams
+    (state download, status summary)."""
+    import torch
+    n = 20_003                        # ragged: the second half ends in a partly filled wavefront
+    s = spe.synth
+    tdt = torch.float64 if prec == 0 else torch.float32
+    mu, cov = s.pose_initial(n)
+    ring = [s.pose_cycle_inputs(n, k, mu[:, :3]) for k in range(3)]
+    dev = [tuple(torch.from_numpy(np.ascontiguousarray(x.reshape(n, -1))).to("cuda", tdt) for x in r) for r in ring]
+    z_ring = torch.stack([d[1] for d in dev]).contiguous()
+    Q_ring = torch.stack([d[2] for d in dev]).contiguous()
+    a_ring = torch.stack([d[0] for d in dev]).contiguous()
+    torch.cuda.synchronize()
+    out = []
+    for split in (1, 0):
+        e = spe.BatchPoseUKF(n, precision=prec, stream="private", split_streams=split)
+        e.initialize(mu, cov)
+        e.set_acceleration(None, 0.01 * np.eye(3))
+        for k in range(3):            # no synchronise between the launches: the halves of consecutive cycles overlap
+            e.bind_acceleration_dev(dev[k][0])
+            e.cycle_dev(0.01, spe.MEAS_POS3, dev[k][1], dev[k][2])
+        st1 = e.status_summary()
+        e.predict(0.02)
+        e.update_dev(spe.MEAS_VEL3, dev[0][1], dev[0][2])
+        e.cycle_multi_dev(3, 0.01, spe.MEAS_POS3, z_ring, Q_ring, 3, 1, in_a_dev=a_ring)
+        m, c, _ = e.state()
+        out.append((m, c, e.status(), st1))
+        e.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert (out[0][2] == out[1][2]).all() and out[0][3] == out[1][3] == 0
+    assert np.isfinite(out[0][0]).all() and max_abs(out[0][0], mu) > 1e-3

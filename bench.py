@@ -91,6 +91,13 @@ def parse():
     ap.add_argument("--cpu-sample-filters", type=int, default=65536)
     ap.add_argument("--cpu-sample-seconds", type=float, default=6.0, help="target CPU time of each all-core sample")
     ap.add_argument("--parity-sample", type=int, default=4096)
+    ap.add_argument("--launcher", choices=["procs", "group"], default="procs",
+                    help="procs (default, the measured contract): one process per GPU, torch.distributed over RCCL. group: ONE "
+                         "process drives all N GPUs through the C-ABI device group (ukfb_group_*: one engine and stream per "
+                         "device, RCCL all-gather of the means from C) -- the shape a C++ host uses")
+    ap.add_argument("--group-devices", default="",
+                    help="--launcher group: comma-separated HIP device per shard (default 0..N-1); naming a device twice "
+                         "rehearses N shards on fewer GPUs (the gather is then skipped: RCCL needs one rank per device)")
     ap.add_argument("--split-streams", type=int, default=1, choices=[0, 1],
                     help="1 (engine default): launches over 16 384 ... 262 143 filters run as two halves on two streams "
                          "(ukfb_config.split_streams); 0: one launch on one stream (same-box A/B)")
@@ -682,8 +689,126 @@ def run_rank(args):
     return 0
 
 
+def run_group(args):
+    """--launcher group: ONE process, N shards through ukfb_group_* (include/ukf_batch.h).  Same workload, same step and
+    the same JSON line as the process-per-GPU path; `value` = all filters x K cycles / wall time between two group syncs."""
+    import numpy as np
+    import torch
+    import slam_pose_estimation_amd as spe
+    if args.workload != "pose":
+        raise SystemExit("--launcher group times the headline workload (--workload pose)")
+    if torch.cuda.device_count() == 0:
+        raise SystemExit("bench.py: no HIP device visible -- the engine has no CPU path")
+    devices = [int(d) for d in args.group_devices.split(",")] if args.group_devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit("--group-devices must name one device per shard (--gpus)")
+    prec = spe.F64 if args.precision == "f64" else spe.F32
+    tdtype = torch.float64 if prec == spe.F64 else torch.float32
+    total = args.filters * args.gpus if args.scaling == "weak" else args.filters
+    grp = spe.UKFGroup(spe.MODEL_POSE, prec, total, devices)
+    grp.configure(split_streams=args.split_streams)
+    CH = 131072
+    rings = []     # per shard: (acc [N_RING][n][3], z, Q [N_RING][n][9]) on the shard's device
+    for sh in grp.shards:
+        dev = torch.device("cuda", sh["device"])
+        n, first = sh["count"], sh["first"]
+        acc_r = torch.empty((N_RING, n, 3), dtype=tdtype, device=dev)
+        z_r = torch.empty((N_RING, n, 3), dtype=tdtype, device=dev)
+        Q_r = torch.empty((N_RING, n, 9), dtype=tdtype, device=dev)
+        for lo in range(0, n, CH):
+            hi = min(n, lo + CH)
+            mu, cov = spe.synth.pose_initial(hi - lo, first=first + lo)
+            grp.initialize(mu, cov, first=first + lo)
+            for k in range(N_RING):
+                acc, z, Q = spe.synth.pose_cycle_inputs(hi - lo, k, mu[:, :3], first=first + lo)
+                acc_r[k, lo:hi] = torch.from_numpy(acc).to(dev, tdtype)
+                z_r[k, lo:hi] = torch.from_numpy(z).to(dev, tdtype)
+                Q_r[k, lo:hi] = torch.from_numpy(Q.reshape(-1, 9)).to(dev, tdtype)
+        rings.append((acc_r, z_r, Q_r))
+
+    def reinitialise():
+        for sh in grp.shards:
+            for lo in range(0, sh["count"], CH):
+                hi = min(sh["count"], lo + CH)
+                mu, cov = spe.synth.pose_initial(hi - lo, first=sh["first"] + lo)
+                grp.initialize(mu, cov, first=sh["first"] + lo)
+    grp.set_acceleration(None, 0.01 * np.eye(3))
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    done = [0]
+
+    def run_cycles(k):
+        for _ in range(k):
+            r = done[0] % N_RING
+            grp.bind_acceleration_dev([x[0][r] for x in rings])
+            grp.cycle_dev(DT, spe.MEAS_POS3, [x[1][r] for x in rings], [x[2][r] for x in rings])
+            done[0] += 1
+
+    # clock pre-roll (the initial state is put back afterwards, as in the process-per-GPU path), warm-up, timed region
+    if args.clock_warmup_seconds > 0:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.clock_warmup_seconds:
+            run_cycles(64)
+            grp.sync()
+        reinitialise()
+        done[0] = 0
+        run_cycles(8)          # (the re-upload took seconds: a short burst before the warm-up steps)
+        grp.sync()
+        reinitialise()
+        done[0] = 0
+    run_cycles(args.warmup)
+    grp.sync()
+    grp.timer_begin()
+    t0 = time.perf_counter()
+    run_cycles(args.steps)
+    kernel_ms_max, kernel_ms_shard = grp.timer_end()
+    grp.sync()
+    elapsed = time.perf_counter() - t0
+    status_or = grp.status_summary()
+    gather_ms = None
+    if len(set(devices)) == len(devices):
+        outs = [torch.empty((total, 13), dtype=tdtype, device=torch.device("cuda", d)) for d in devices]
+        grp.gather_means(outs)      # first call: communicator + staging
+        grp.sync()
+        g0 = time.perf_counter()
+        grp.gather_means(outs)
+        grp.sync()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        m_all, _, _ = grp.state(0, min(total, 4096))
+        assert np.array_equal(outs[-1][: m_all.shape[0]].double().cpu().numpy(), m_all)
+    parity = None
+    if not args.no_parity:
+        eng0 = grp.shards[0]["engine"]
+        parity = parity_check(args, spe, eng0, grp.shards[0]["first"], min(args.parity_sample, grp.shards[0]["count"]), done[0], False)
+    tsize = 8 if prec == spe.F64 else 4
+    per = max(s["count"] for s in grp.shards)
+    alg_bytes_launch = ALG_SCALARS_POSE * tsize * per
+    kernel_ms_launch = kernel_ms_max / args.steps
+    info = grp.shards[0]["engine"].last_launch_info()
+    out = {"metric": "UKF predict+update filter-cycles/s, PoseWithVelocity filters", "value": total * args.steps / elapsed,
+           "unit": "filter-cycles/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+           "dtype": args.precision, "data": "synthetic", "launcher": "group",
+           "config": {"workload": f"{total} PoseWithVelocity UKF filters, fused predict(acc branch, dt=0.01)+PositionMeasurement "
+                                  f"update per step, {args.precision}, {per} filters per shard, one process / {args.gpus} shards "
+                                  f"on devices {devices} (ukfb_group_*)",
+                      "filters": total, "filters_per_gpu": per, "devices": devices, "parallelism": f"filter-sharded x{args.gpus}"},
+           "roofline": {"bound": "hbm", "achieved": alg_bytes_launch / (kernel_ms_launch * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg_bytes_launch / (kernel_ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": info["kernel"], "kernel_ms_per_launch": kernel_ms_launch,
+                        "kernel_ms_per_launch_by_shard": [x / args.steps for x in kernel_ms_shard],
+                        "note": "per device: the slowest shard's HIP-event time per cycle and the bytes of one shard"},
+           "status_or": status_or, "rccl_ranks": (len(devices) if gather_ms is not None else None), "gather_ms": gather_ms,
+           "parity": parity, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    grp.close()
+    return 0
+
+
 def main():
     args = parse()
+    if args.launcher == "group" and "RANK" not in os.environ and not args.plumbing_only:
+        return run_group(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_children(args)
     return run_rank(args)

@@ -122,6 +122,56 @@ public:
     void getRotationRates(int64_t first, int64_t count, double* out) { check(ukfb_orient_get_rotation_rate(engine, first, count, out)); }
 };
 
+/** One host process, several MI355X: `total` independent PoseUKF filters in contiguous shards, one engine per device
+ *  (ukfb_group_* of ukf_batch.h).  Filters never read each other (UnscentedKalmanFilter.hpp:150), so the shards need no
+ *  collective on the data path; gatherMeans is the one exchange (RCCL all-gather over xGMI).  Whole-batch host arrays are
+ *  in batch numbering; device-pointer arguments are one pointer PER SHARD (memory on that shard's device). */
+class ShardedBatchPoseUKF
+{
+public:
+    ShardedBatchPoseUKF(int64_t total, const std::vector<int>& devices, int precision = UKFB_F64) : group(NULL), n(total)
+    {
+        if (ukfb_group_create(&group, UKFB_MODEL_POSE, precision, total, devices.data(), static_cast<int>(devices.size())) != UKFB_OK)
+            throw std::runtime_error(std::string("pose_estimation: MI355X engine group unavailable: ") + ukfb_last_error());
+        double R[144] = {0};   // PoseUKF.cpp:103-107
+        for (int k = 0; k < 3; ++k) { R[k * 13] = 0.01; R[(3 + k) * 13] = 0.001; R[(6 + k) * 13] = 0.00001; R[(9 + k) * 13] = 0.00001; }
+        check(ukfb_group_set_process_noise(group, R));
+    }
+    ~ShardedBatchPoseUKF() { ukfb_group_destroy(group); }
+
+    int64_t capacity() const { return n; }
+    int shards() const { return ukfb_group_size(group); }
+    ukfb_group* handle() { return group; }
+    /** engine of one shard (every single-engine call of ukf_batch.h applies), its device and filter range */
+    ukfb_engine* shard(int r, int* device = NULL, int64_t* first = NULL, int64_t* count = NULL)
+    {
+        ukfb_engine* e = NULL;
+        check(ukfb_group_shard(group, r, &e, device, first, count));
+        return e;
+    }
+    void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov) { check(ukfb_group_initialize(group, first, count, mu, cov)); }
+    void getCurrentStates(int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised = NULL) { check(ukfb_group_get_state(group, first, count, mu, cov, initialised)); }
+    void setProcessNoiseCovariance(const double* R) { check(ukfb_group_set_process_noise(group, R)); }
+    void setAccelerations(int64_t first, int64_t count, const double* acc_mu, const double* acc_cov3x3) { check(ukfb_group_pose_set_acceleration(group, first, count, acc_mu, acc_cov3x3)); }
+    void predictionStep(double delta_t) { check(ukfb_group_predict(group, delta_t)); }
+    void integrateMeasurements(int model, const double* z, const double* Q) { check(ukfb_group_update(group, model, z, Q)); }
+    void cycle(double delta_t, int model, const double* z, const double* Q) { check(ukfb_group_cycle(group, delta_t, model, z, Q)); }
+    /** samples already resident on the devices: z_dev[r] / Q_dev[r] on shard r's device, engine precision */
+    void cycleDev(double delta_t, int model, const void* const* z_dev, const void* const* Q_dev) { check(ukfb_group_cycle_dev(group, delta_t, model, z_dev, Q_dev)); }
+    void bindAccelerationsDev(const void* const* acc_mu_dev) { check(ukfb_group_pose_bind_acceleration_dev(group, acc_mu_dev)); }
+    /** RCCL all-gather: out_dev[r] ([total][13], engine precision, on shard r's device) receives every filter's mean */
+    void gatherMeans(void* const* out_dev) { check(ukfb_group_gather_means(group, out_dev)); }
+    uint32_t statusSummary() { uint32_t v = 0; check(ukfb_group_get_status_summary(group, &v)); return v; }
+    void sync() { check(ukfb_group_sync(group)); }
+
+private:
+    void check(int rc) const { if (rc != UKFB_OK) throw std::runtime_error(std::string("pose_estimation engine group: ") + ukfb_last_error()); }
+    ukfb_group* group;
+    int64_t n;
+    ShardedBatchPoseUKF(const ShardedBatchPoseUKF&);
+    ShardedBatchPoseUKF& operator=(const ShardedBatchPoseUKF&);
+};
+
 }
 
 #endif

@@ -288,6 +288,56 @@ int ukfb_process_events_dev(ukfb_engine* e, int64_t n_events, const int64_t* fil
                             const int32_t* meas_model_dev, const void* z_dev, const void* Q_dev, uint32_t* status_or,
                             int64_t* rounds);
 
+
+/* ---- device groups: one host process, several MI355X ------------------------------------------------------------------ */
+/* north_star's multi-GPU shape for a C++ host.  The filters of a batch are independent -- every filter of the reference owns
+ * its own `ukf` object (src/UnscentedKalmanFilter.hpp:150) -- so `total_filters` split into contiguous shards (the first
+ * total % n shards own one filter more; ukfb_group_shard_range), one engine with its own stream per device, and NO
+ * collective on the data path.  The calls below fan out to the shards from the calling thread: the hot-path calls only
+ * enqueue (the devices then run concurrently), ukfb_group_sync waits for all of them.  The one exchange is the result
+ * gather, an RCCL all-gather of the means over xGMI.  Errors: the usual codes, text in ukfb_last_error().
+ * `devices` may name a device more than once (several shards on one GPU: everything but the gather works). */
+typedef struct ukfb_group ukfb_group;
+int ukfb_group_shard_range(int64_t total, int n_shards, int shard, int64_t* first, int64_t* count);
+int ukfb_group_create(ukfb_group** out, int model, int precision, int64_t total_filters, const int* devices, int n_devices);
+int ukfb_group_destroy(ukfb_group* g);
+int ukfb_group_size(const ukfb_group* g);   /* shards, -1 for NULL */
+/* shard `shard`: its engine (every per-engine call above applies to it), device, first filter and filter count */
+int ukfb_group_shard(ukfb_group* g, int shard, ukfb_engine** engine, int* device, int64_t* first, int64_t* count);
+int ukfb_group_set_config(ukfb_group* g, const ukfb_config* cfg);
+/* whole-batch host arrays, [first, first + count) in BATCH numbering, routed to the shards that own the filters */
+int ukfb_group_initialize(ukfb_group* g, int64_t first, int64_t count, const double* mu, const double* cov);
+int ukfb_group_get_state(ukfb_group* g, int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised);
+int ukfb_group_get_status(ukfb_group* g, int64_t first, int64_t count, uint32_t* status);
+int ukfb_group_get_status_summary(ukfb_group* g, uint32_t* or_of_all);
+int ukfb_group_set_process_noise(ukfb_group* g, const double* R);
+int ukfb_group_pose_set_acceleration(ukfb_group* g, int64_t first, int64_t count, const double* acc_mu, const double* acc_cov);
+int ukfb_group_orient_set_params(ukfb_group* g, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3]);
+int ukfb_group_orient_set_inputs(ukfb_group* g, int64_t first, int64_t count, const double* gyro, const double* acc);
+/* hot path from host arrays over the whole batch (z [total][3], Q [total][3][3]) */
+int ukfb_group_predict(ukfb_group* g, double dt);
+int ukfb_group_update(ukfb_group* g, int meas_model, const double* z, const double* Q);
+int ukfb_group_cycle(ukfb_group* g, double dt, int meas_model, const double* z, const double* Q);
+/* hot path from device-resident inputs: arrays of one device pointer PER SHARD (index = shard, memory on that shard's
+ * device, engine precision, sized for the shard's filters) -- the shapes of ukfb_cycle_dev / ukfb_cycle_multi_dev /
+ * ukfb_pose_bind_acceleration_dev / ukfb_orient_bind_inputs_dev */
+int ukfb_group_pose_bind_acceleration_dev(ukfb_group* g, const void* const* acc_mu_dev);
+int ukfb_group_orient_bind_inputs_dev(ukfb_group* g, const void* const* gyro_dev, const void* const* acc_dev);
+int ukfb_group_cycle_dev(ukfb_group* g, double dt, int meas_model, const void* const* z_dev, const void* const* Q_dev);
+int ukfb_group_cycle_multi_dev(ukfb_group* g, int cycles, double dt, int meas_model, int slots, int first_slot,
+                               const void* const* in_a_dev, const void* const* in_b_dev, const void* const* z_dev,
+                               const void* const* Q_dev);
+int ukfb_group_sync(ukfb_group* g);
+/* HIP-event timing on every shard's stream; elapsed_ms_max = the slowest shard, elapsed_ms_per_shard [shards] may be NULL */
+int ukfb_group_timer_begin(ukfb_group* g);
+int ukfb_group_timer_end(ukfb_group* g, float* elapsed_ms_max, float* elapsed_ms_per_shard);
+/* Result gather: out_dev[shard] -- memory on that shard's device, engine precision, [total_filters][S] -- receives the mean
+ * states of ALL filters in batch order on every device: ncclAllGather over one communicator per device (ncclCommInitAll at
+ * the first call; RCCL is loaded at run time, librccl.so.1).  Stream-ordered after the launches enqueued so far; complete
+ * after ukfb_group_sync.  Gather at the end of a run or every K cycles, not per cycle: at 131 072 Pose filters per device
+ * the means are 6.8 MB (fp32) per shard, about the duration of one cycle over xGMI.  Needs one shard per device. */
+int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev);
+
 /* ---- measurement of the engine itself ---------------------------------------------------- */
 /* name, dynamic LDS bytes per workgroup, filters per workgroup and grid size of the kernel the
  * most recent predict/update/cycle call launched (for profiles/ and bench.py) */

@@ -10,4 +10,4 @@ from . import synth  # noqa: F401
 from .sharding import gather_means, shard_range  # noqa: F401
 from .build import build_engine  # noqa: F401
 from .engine import *  # noqa: F401,F403
-from .engine import BatchOrientationUKF, BatchPoseUKF, BatchUKF, Config, UkfbError, layout_supported, load_library  # noqa: F401
+from .engine import BatchOrientationUKF, BatchPoseUKF, BatchUKF, Config, UKFGroup, UkfbError, layout_supported, load_library  # noqa: F401

@@ -498,6 +498,7 @@ namespace ukfb {
 void set_error(const char* what, hipError_t err) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(err);
 }
+void set_error_text(const std::string& text) { g_last_error = text; }
 }  // namespace ukfb
 
 // Waiting by polling: hipEventSynchronize / hipStreamSynchronize sleep on an interrupt and were measured to
@@ -1536,12 +1537,14 @@ int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capa
 
 int ukfb_timer_begin(ukfb_engine* e) {
     if (!e) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventRecord(e->ev0, ukfb::main_stream(e)));
     return UKFB_OK;
 }
 
 int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms) {
     if (!e || !elapsed_ms) return UKFB_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(e->device));
     if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
     HIP_TRY(hipEventRecord(e->ev1, ukfb::main_stream(e)));
     {

@@ -120,6 +120,7 @@ int launch_orient_f64(ukfb_engine* e, const LaunchReq& r);
 int launch_orient_f32(ukfb_engine* e, const LaunchReq& r);
 
 void set_error(const char* what, hipError_t err);
+void set_error_text(const std::string& text);   // what ukfb_last_error() returns on this thread
 
 // The engine's stream for anything but a split launch: first makes it wait for the second half of the last split launch.
 inline hipStream_t main_stream(ukfb_engine* e) {

@@ -1,0 +1,439 @@
+// ukf_group.hip -- device groups: ONE host process drives the engines of several MI355X (include/ukf_batch.h, ukfb_group_*).
+//
+// north_star's multi-GPU shape for a C++ host: the filters of a batch are independent (every filter of the reference
+// owns its own ukf object, src/UnscentedKalmanFilter.hpp:150), so a batch splits into contiguous shards, one engine and
+// one stream per device, with NO collective on the data path.  The only exchange is the result gather, an RCCL all-gather
+// of the mean states over xGMI (ncclCommInitAll + ncclAllGather, /opt/rocm/include/rccl/rccl.h:236,678).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1 at the first gather): libukf_batch.so carries no link-time
+// dependency on it, and a process that already holds an RCCL (PyTorch ships one under the same soname) shares that copy
+// instead of loading a second one.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "ukf_engine.hpp"
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString; }
+};
+
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        // a copy that is already in the process first (same soname), then the system's
+        x.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!x.lib) x.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!x.lib) x.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!x.lib) x.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (x.lib) {
+            x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(x.lib, "ncclCommInitAll"));
+            x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.lib, "ncclCommDestroy"));
+            x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.lib, "ncclAllGather"));
+            x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.lib, "ncclGroupStart"));
+            x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.lib, "ncclGroupEnd"));
+            x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.lib, "ncclGetErrorString"));
+        }
+        return x;
+    }();
+    return r;
+}
+
+}  // namespace
+
+struct ukfb_group {
+    int model = 0, prec = 0, S = 0, D = 0;
+    size_t tsize = 8;
+    int64_t total = 0;
+    std::vector<int> devices;
+    std::vector<ukfb_engine*> engines;
+    std::vector<int64_t> first, count;
+    // result gather: one communicator per shard (created at the first gather), padded staging per shard
+    std::vector<ncclComm_t> comms;
+    std::vector<void*> send_pad, recv_pad;
+    int64_t max_count = 0;
+};
+
+namespace {
+
+int gfail(int code, const std::string& msg) {
+    ukfb::set_error_text(msg);   // one error channel: ukfb_last_error()
+    return code;
+}
+
+// rc of an engine call: the engine has left its text in ukfb_last_error() already
+int efail(int rc) { return rc; }
+
+bool shard_ok(const ukfb_group* g, int r) { return g && r >= 0 && r < int(g->engines.size()); }
+
+// [first, first + count) of the batch cut by shard r: (offset inside the caller's arrays, offset inside the shard, length)
+struct Cut {
+    int64_t src, dst, len;
+};
+Cut cut(const ukfb_group* g, int r, int64_t first, int64_t count) {
+    const int64_t lo = std::max(first, g->first[r]), hi = std::min(first + count, g->first[r] + g->count[r]);
+    return {lo - first, lo - g->first[r], std::max<int64_t>(0, hi - lo)};
+}
+
+void release_gather(ukfb_group* g) {
+    for (size_t r = 0; r < g->comms.size(); ++r)
+        if (g->comms[r]) (void)rccl().CommDestroy(g->comms[r]);
+    g->comms.clear();
+    for (size_t r = 0; r < g->send_pad.size(); ++r) {
+        (void)hipSetDevice(g->devices[r]);
+        if (g->send_pad[r]) (void)hipFree(g->send_pad[r]);
+        if (g->recv_pad[r]) (void)hipFree(g->recv_pad[r]);
+    }
+    g->send_pad.clear();
+    g->recv_pad.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ukfb_group_shard_range(int64_t total, int n_shards, int shard, int64_t* first, int64_t* count) {
+    if (total < 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return UKFB_ERR_INVALID_ARG;
+    const int64_t base = total / n_shards, extra = total % n_shards;
+    if (count) *count = base + (shard < extra ? 1 : 0);
+    if (first) *first = shard * base + std::min<int64_t>(shard, extra);
+    return UKFB_OK;
+}
+
+int ukfb_group_create(ukfb_group** out, int model, int precision, int64_t total_filters, const int* devices, int n_devices) {
+    if (!out || !devices || n_devices <= 0 || total_filters < n_devices)
+        return gfail(UKFB_ERR_INVALID_ARG, "ukfb_group_create: need devices and at least one filter per shard");
+    *out = nullptr;
+    ukfb_group* g = new (std::nothrow) ukfb_group();
+    if (!g) return gfail(UKFB_ERR_INVALID_ARG, "out of host memory");
+    g->model = model;
+    g->prec = precision;
+    g->total = total_filters;
+    g->tsize = precision == UKFB_F64 ? 8 : 4;
+    for (int r = 0; r < n_devices; ++r) {
+        int64_t f = 0, c = 0;
+        ukfb_group_shard_range(total_filters, n_devices, r, &f, &c);
+        ukfb_engine* e = nullptr;
+        const int rc = ukfb_create(&e, model, precision, c, devices[r], nullptr);   // its own stream on its own device
+        if (rc) {
+            const std::string msg = ukfb_last_error();
+            ukfb_group_destroy(g);
+            ukfb::set_error_text(msg);
+            return rc;
+        }
+        g->devices.push_back(devices[r]);
+        g->engines.push_back(e);
+        g->first.push_back(f);
+        g->count.push_back(c);
+        g->max_count = std::max(g->max_count, c);
+    }
+    ukfb_describe(g->engines[0], nullptr, nullptr, nullptr, &g->S, &g->D, nullptr);
+    *out = g;
+    return UKFB_OK;
+}
+
+int ukfb_group_destroy(ukfb_group* g) {
+    if (!g) return UKFB_OK;
+    release_gather(g);
+    int rc = UKFB_OK;
+    for (ukfb_engine* e : g->engines) {
+        const int r = ukfb_destroy(e);
+        rc = rc ? rc : r;
+    }
+    delete g;
+    return rc;
+}
+
+int ukfb_group_size(const ukfb_group* g) { return g ? int(g->engines.size()) : -1; }
+
+int ukfb_group_shard(ukfb_group* g, int shard, ukfb_engine** engine, int* device, int64_t* first, int64_t* count) {
+    if (!shard_ok(g, shard)) return gfail(UKFB_ERR_INVALID_ARG, "ukfb_group_shard: no such shard");
+    if (engine) *engine = g->engines[shard];
+    if (device) *device = g->devices[shard];
+    if (first) *first = g->first[shard];
+    if (count) *count = g->count[shard];
+    return UKFB_OK;
+}
+
+int ukfb_group_set_config(ukfb_group* g, const ukfb_config* cfg) {
+    if (!g || !cfg) return UKFB_ERR_INVALID_ARG;
+    for (ukfb_engine* e : g->engines) {
+        const int rc = ukfb_set_config(e, cfg);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_initialize(ukfb_group* g, int64_t first, int64_t count, const double* mu, const double* cov) {
+    if (!g || !mu || !cov || first < 0 || count < 0 || first + count > g->total)
+        return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_initialize: bad range");
+    const size_t DD = size_t(g->D) * g->D;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const Cut c = cut(g, int(r), first, count);
+        if (!c.len) continue;
+        const int rc = ukfb_initialize(g->engines[r], c.dst, c.len, mu + size_t(c.src) * g->S, cov + size_t(c.src) * DD);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_get_state(ukfb_group* g, int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised) {
+    if (!g || first < 0 || count < 0 || first + count > g->total)
+        return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_get_state: bad range");
+    const size_t DD = size_t(g->D) * g->D;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const Cut c = cut(g, int(r), first, count);
+        if (!c.len) continue;
+        const int rc = ukfb_get_state(g->engines[r], c.dst, c.len, mu ? mu + size_t(c.src) * g->S : nullptr,
+                                      cov ? cov + size_t(c.src) * DD : nullptr, initialised ? initialised + c.src : nullptr);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_get_status(ukfb_group* g, int64_t first, int64_t count, uint32_t* status) {
+    if (!g || !status || first < 0 || count < 0 || first + count > g->total)
+        return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_get_status: bad range");
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const Cut c = cut(g, int(r), first, count);
+        if (!c.len) continue;
+        const int rc = ukfb_get_status(g->engines[r], c.dst, c.len, status + c.src);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_get_status_summary(ukfb_group* g, uint32_t* or_of_all) {
+    if (!g || !or_of_all) return UKFB_ERR_INVALID_ARG;
+    uint32_t all = 0;
+    for (ukfb_engine* e : g->engines) {
+        uint32_t v = 0;
+        const int rc = ukfb_get_status_summary(e, &v);
+        if (rc) return efail(rc);
+        all |= v;
+    }
+    *or_of_all = all;
+    return UKFB_OK;
+}
+
+int ukfb_group_set_process_noise(ukfb_group* g, const double* R) {
+    if (!g || !R) return UKFB_ERR_INVALID_ARG;
+    for (ukfb_engine* e : g->engines) {
+        const int rc = ukfb_set_process_noise(e, R);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_pose_set_acceleration(ukfb_group* g, int64_t first, int64_t count, const double* acc_mu, const double* acc_cov) {
+    if (!g || first < 0 || count < 0 || first + count > g->total)
+        return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_pose_set_acceleration: bad range");
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const Cut c = cut(g, int(r), first, count);
+        // (the batch-uniform covariance goes to every shard, also to one the range does not touch)
+        const int rc = ukfb_pose_set_acceleration(g->engines[r], c.len ? c.dst : 0, c.len, (acc_mu && c.len) ? acc_mu + size_t(c.src) * 3 : nullptr,
+                                                  acc_cov);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_orient_set_params(ukfb_group* g, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3]) {
+    if (!g) return UKFB_ERR_INVALID_ARG;
+    for (ukfb_engine* e : g->engines) {
+        const int rc = ukfb_orient_set_params(e, gyro_bias_tau, acc_bias_tau, earth_rotation);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_orient_set_inputs(ukfb_group* g, int64_t first, int64_t count, const double* gyro, const double* acc) {
+    if (!g || first < 0 || count < 0 || first + count > g->total)
+        return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_orient_set_inputs: bad range");
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const Cut c = cut(g, int(r), first, count);
+        if (!c.len) continue;
+        const int rc = ukfb_orient_set_inputs(g->engines[r], c.dst, c.len, gyro ? gyro + size_t(c.src) * 3 : nullptr,
+                                              acc ? acc + size_t(c.src) * 3 : nullptr);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+// ---- the hot path, fanned out: every call below only ENQUEUES on the shards' streams (one after the other from this
+// thread, the devices then run concurrently) and returns; ukfb_group_sync waits for all of them
+int ukfb_group_cycle_dev(ukfb_group* g, double dt, int meas_model, const void* const* z_dev, const void* const* Q_dev) {
+    if (!g || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_cycle_dev(g->engines[r], dt, meas_model, nullptr, z_dev[r], Q_dev[r]);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_cycle_multi_dev(ukfb_group* g, int cycles, double dt, int meas_model, int slots, int first_slot,
+                               const void* const* in_a_dev, const void* const* in_b_dev, const void* const* z_dev,
+                               const void* const* Q_dev) {
+    if (!g || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_cycle_multi_dev(g->engines[r], cycles, dt, meas_model, slots, first_slot, in_a_dev ? in_a_dev[r] : nullptr,
+                                            in_b_dev ? in_b_dev[r] : nullptr, z_dev[r], Q_dev[r]);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_pose_bind_acceleration_dev(ukfb_group* g, const void* const* acc_mu_dev) {
+    if (!g) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_pose_bind_acceleration_dev(g->engines[r], acc_mu_dev ? acc_mu_dev[r] : nullptr);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_orient_bind_inputs_dev(ukfb_group* g, const void* const* gyro_dev, const void* const* acc_dev) {
+    if (!g) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_orient_bind_inputs_dev(g->engines[r], gyro_dev ? gyro_dev[r] : nullptr, acc_dev ? acc_dev[r] : nullptr);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+// host arrays over the whole batch (z [total][3], Q [total][3][3]): every shard uploads and launches its range
+int ukfb_group_cycle(ukfb_group* g, double dt, int meas_model, const double* z, const double* Q) {
+    if (!g || !z || !Q) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_cycle(g->engines[r], dt, meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_predict(ukfb_group* g, double dt) {
+    if (!g) return UKFB_ERR_INVALID_ARG;
+    for (ukfb_engine* e : g->engines) {
+        const int rc = ukfb_predict(e, dt);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_update(ukfb_group* g, int meas_model, const double* z, const double* Q) {
+    if (!g || !z || !Q) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_update(g->engines[r], meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9, nullptr);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_sync(ukfb_group* g) {
+    if (!g) return UKFB_ERR_INVALID_ARG;
+    int rc = UKFB_OK;
+    for (ukfb_engine* e : g->engines) {
+        const int r = ukfb_sync(e);
+        if (r && !rc) rc = efail(r);
+    }
+    return rc;
+}
+
+// HIP-event timing over all shards: begin / end bracket a region on every shard's stream, elapsed = the slowest shard
+int ukfb_group_timer_begin(ukfb_group* g) {
+    if (!g) return UKFB_ERR_INVALID_ARG;
+    for (ukfb_engine* e : g->engines) {
+        const int rc = ukfb_timer_begin(e);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+int ukfb_group_timer_end(ukfb_group* g, float* elapsed_ms_max, float* elapsed_ms_per_shard) {
+    if (!g || !elapsed_ms_max) return UKFB_ERR_INVALID_ARG;
+    float mx = 0.f;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        float ms = 0.f;
+        const int rc = ukfb_timer_end(g->engines[r], &ms);
+        if (rc) return efail(rc);
+        if (elapsed_ms_per_shard) elapsed_ms_per_shard[r] = ms;
+        mx = std::max(mx, ms);
+    }
+    *elapsed_ms_max = mx;
+    return UKFB_OK;
+}
+
+// ---- result gather: RCCL all-gather of the mean states over xGMI.  out_dev[r] (device r, engine precision, [total][S])
+// receives the means of ALL filters in batch order.  Shards may differ by one filter (ukfb_group_shard_range): the
+// collective runs on buffers padded to the largest shard, one device-to-device copy per shard compacts the result.
+int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
+    if (!g || !out_dev) return UKFB_ERR_INVALID_ARG;
+    const size_t n = g->engines.size();
+    Rccl& rc = rccl();
+    if (!rc.ok()) return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: RCCL (librccl.so.1) could not be loaded");
+    for (size_t a = 0; a < n; ++a)
+        for (size_t b = a + 1; b < n; ++b)
+            if (g->devices[a] == g->devices[b])
+                return gfail(UKFB_ERR_INVALID_ARG, "ukfb_group_gather_means: two shards share a device (RCCL needs one rank per device); "
+                                                   "read the shards with ukfb_group_get_state instead");
+    const size_t row = size_t(g->S) * g->tsize, pad_bytes = size_t(g->max_count) * row;
+    if (g->comms.empty()) {
+        g->comms.assign(n, nullptr);
+        const ncclResult_t st = rc.CommInitAll(g->comms.data(), int(n), g->devices.data());
+        if (st != ncclSuccess) {
+            g->comms.clear();
+            return gfail(UKFB_ERR_HIP, std::string("ncclCommInitAll: ") + rc.GetErrorString(st));
+        }
+        g->send_pad.assign(n, nullptr);
+        g->recv_pad.assign(n, nullptr);
+        for (size_t r = 0; r < n; ++r) {
+            if (hipSetDevice(g->devices[r]) != hipSuccess || hipMalloc(&g->send_pad[r], pad_bytes) != hipSuccess ||
+                hipMalloc(&g->recv_pad[r], pad_bytes * n) != hipSuccess || hipMemset(g->send_pad[r], 0, pad_bytes) != hipSuccess) {
+                release_gather(g);
+                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging allocation failed");
+            }
+        }
+    }
+    // every shard: mean -> padded send buffer on its own stream (ordered after the launches enqueued so far)
+    std::vector<hipStream_t> streams(n);
+    for (size_t r = 0; r < n; ++r) {
+        ukfb_engine* e = g->engines[r];
+        if (hipSetDevice(g->devices[r]) != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
+        streams[r] = ukfb::main_stream(e);
+        if (hipMemcpyAsync(g->send_pad[r], e->mu, size_t(g->count[r]) * row, hipMemcpyDeviceToDevice, streams[r]) != hipSuccess)
+            return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging copy failed");
+    }
+    const ncclDataType_t dt = g->prec == UKFB_F64 ? ncclFloat64 : ncclFloat32;
+    ncclResult_t st = rc.GroupStart();
+    for (size_t r = 0; r < n && st == ncclSuccess; ++r)
+        st = rc.AllGather(g->send_pad[r], g->recv_pad[r], size_t(g->max_count) * g->S, dt, g->comms[r], streams[r]);
+    const ncclResult_t st2 = rc.GroupEnd();
+    if (st != ncclSuccess || st2 != ncclSuccess)
+        return gfail(UKFB_ERR_HIP, std::string("ncclAllGather: ") + rc.GetErrorString(st != ncclSuccess ? st : st2));
+    for (size_t r = 0; r < n; ++r) {
+        if (hipSetDevice(g->devices[r]) != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
+        for (size_t s = 0; s < n; ++s)
+            if (hipMemcpyAsync(static_cast<char*>(out_dev[r]) + size_t(g->first[s]) * row,
+                               static_cast<const char*>(g->recv_pad[r]) + s * pad_bytes, size_t(g->count[s]) * row,
+                               hipMemcpyDeviceToDevice, streams[r]) != hipSuccess)
+                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: compaction copy failed");
+    }
+    return UKFB_OK;   // stream-ordered: ukfb_group_sync (or the shard's stream) completes it
+}
+
+}  // extern "C"

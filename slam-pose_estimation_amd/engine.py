@@ -48,6 +48,14 @@ EXPORTS = [
     "ukfb_last_launch_info",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
     "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
+    # device groups (one process, several GPUs)
+    "ukfb_group_shard_range", "ukfb_group_create", "ukfb_group_destroy", "ukfb_group_size", "ukfb_group_shard",
+    "ukfb_group_set_config", "ukfb_group_initialize", "ukfb_group_get_state", "ukfb_group_get_status",
+    "ukfb_group_get_status_summary", "ukfb_group_set_process_noise", "ukfb_group_pose_set_acceleration",
+    "ukfb_group_orient_set_params", "ukfb_group_orient_set_inputs", "ukfb_group_predict", "ukfb_group_update",
+    "ukfb_group_cycle", "ukfb_group_pose_bind_acceleration_dev", "ukfb_group_orient_bind_inputs_dev",
+    "ukfb_group_cycle_dev", "ukfb_group_cycle_multi_dev", "ukfb_group_sync", "ukfb_group_timer_begin",
+    "ukfb_group_timer_end", "ukfb_group_gather_means",
 ]
 BODY_STATE_SCALARS = 49
 
@@ -459,3 +467,156 @@ class BatchOrientationUKF(BatchUKF):
         n = mu.shape[0]
         acc = np.zeros((n, 3)); acc[:, 2] = mu[:, 13]
         self.set_orient_inputs(gyro=np.zeros((n, 3)), acc=acc, first=first)
+
+
+class _ShardView(BatchUKF):
+    """A shard's engine seen through the per-engine binding (the group owns the handle: close() is a no-op)."""
+
+    def __init__(self, lib, handle, model, precision, capacity, device):   # noqa: D401 (no ukfb_create here)
+        self._lib, self._h = lib, handle
+        self.model, self.precision, self.capacity, self.device = model, precision, int(capacity), device
+        self.S = 13 if model == MODEL_POSE else 14
+        self.D = 12 if model == MODEL_POSE else 13
+        self.PK = self.D * (self.D + 1) // 2
+        self.dtype = np.float64 if precision == F64 else np.float32
+        self.stream_kind = "private"
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class UKFGroup:
+    """One process, several GPUs: `total` independent filters in contiguous shards, one engine per device
+    (ukfb_group_* of include/ukf_batch.h).  Mirrors pose_estimation::ShardedBatchPoseUKF (include/pose_estimation/Batch.hpp)."""
+
+    def __init__(self, model: int, precision: int, total: int, devices):
+        self._lib = load_library()
+        self._g = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _chk(self._lib.ukfb_group_create(C.byref(self._g), C.c_int(model), C.c_int(precision), C.c_int64(total), devs,
+                                         C.c_int(len(devices))), "ukfb_group_create")
+        self.model, self.precision, self.total = model, precision, int(total)
+        self.S = 13 if model == MODEL_POSE else 14
+        self.D = 12 if model == MODEL_POSE else 13
+        self.n = int(self._lib.ukfb_group_size(self._g))
+        self.shards = []
+        for r in range(self.n):
+            h, dev, first, count = C.c_void_p(), C.c_int(0), C.c_int64(0), C.c_int64(0)
+            _chk(self._lib.ukfb_group_shard(self._g, C.c_int(r), C.byref(h), C.byref(dev), C.byref(first), C.byref(count)),
+                 "ukfb_group_shard")
+            self.shards.append({"engine": _ShardView(self._lib, h, model, precision, count.value, dev.value),
+                                "device": dev.value, "first": first.value, "count": count.value})
+        if model == MODEL_POSE:   # PoseUKF ctor defaults (PoseUKF.cpp:103-107), as BatchPoseUKF
+            self.set_process_noise(np.diag([0.01] * 3 + [0.001] * 3 + [0.00001] * 3 + [0.00001] * 3))
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self._lib.ukfb_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ptrs(self, xs):
+        if xs is None:
+            return None
+        assert len(xs) == self.n, "one device pointer per shard"
+        return (C.c_void_p * self.n)(*[(_devptr(x).value if x is not None else None) for x in xs])
+
+    def configure(self, **kw):
+        c = self.shards[0]["engine"].config()
+        for k, v in kw.items():
+            setattr(c, k, v)
+        _chk(self._lib.ukfb_group_set_config(self._g, C.byref(c)), "ukfb_group_set_config")
+
+    def initialize(self, mu, cov, first: int = 0):
+        mu = _f64(mu, (-1, self.S)); cov = _f64(cov, (-1, self.D, self.D))
+        _chk(self._lib.ukfb_group_initialize(self._g, C.c_int64(first), C.c_int64(mu.shape[0]), _pd(mu), _pd(cov)),
+             "ukfb_group_initialize")
+
+    def state(self, first: int = 0, count: Optional[int] = None):
+        count = self.total - first if count is None else count
+        mu = np.empty((count, self.S)); cov = np.empty((count, self.D, self.D)); init = np.empty(count, dtype=np.uint8)
+        _chk(self._lib.ukfb_group_get_state(self._g, C.c_int64(first), C.c_int64(count), _pd(mu), _pd(cov),
+                                            init.ctypes.data_as(C.POINTER(C.c_uint8))), "ukfb_group_get_state")
+        return mu, cov, init.astype(bool)
+
+    def status(self, first: int = 0, count: Optional[int] = None):
+        count = self.total - first if count is None else count
+        st = np.empty(count, dtype=np.uint32)
+        _chk(self._lib.ukfb_group_get_status(self._g, C.c_int64(first), C.c_int64(count), st.ctypes.data_as(C.POINTER(C.c_uint32))),
+             "ukfb_group_get_status")
+        return st
+
+    def status_summary(self) -> int:
+        v = C.c_uint32(0)
+        _chk(self._lib.ukfb_group_get_status_summary(self._g, C.byref(v)), "ukfb_group_get_status_summary")
+        return int(v.value)
+
+    def set_process_noise(self, R):
+        _chk(self._lib.ukfb_group_set_process_noise(self._g, _pd(_f64(R, (self.D, self.D)))), "ukfb_group_set_process_noise")
+
+    def set_acceleration(self, acc_mu=None, acc_cov=None, first: int = 0):
+        am = _f64(acc_mu, (-1, 3)) if acc_mu is not None else None
+        ac = _f64(acc_cov, (3, 3)) if acc_cov is not None else None
+        _chk(self._lib.ukfb_group_pose_set_acceleration(self._g, C.c_int64(first), C.c_int64(am.shape[0] if am is not None else 0),
+                                                        _pd(am), _pd(ac)), "ukfb_group_pose_set_acceleration")
+
+    def set_orient_params(self, gyro_bias_tau: float, acc_bias_tau: float, earth_rotation):
+        _chk(self._lib.ukfb_group_orient_set_params(self._g, C.c_double(gyro_bias_tau), C.c_double(acc_bias_tau),
+                                                    _pd(_f64(earth_rotation, (3,)))), "ukfb_group_orient_set_params")
+
+    def set_orient_inputs(self, gyro=None, acc=None, first: int = 0):
+        g = _f64(gyro, (-1, 3)) if gyro is not None else None
+        a = _f64(acc, (-1, 3)) if acc is not None else None
+        n = g.shape[0] if g is not None else (a.shape[0] if a is not None else 0)
+        _chk(self._lib.ukfb_group_orient_set_inputs(self._g, C.c_int64(first), C.c_int64(n), _pd(g), _pd(a)),
+             "ukfb_group_orient_set_inputs")
+
+    def predict(self, dt: float):
+        _chk(self._lib.ukfb_group_predict(self._g, C.c_double(dt)), "ukfb_group_predict")
+
+    def update(self, meas_model: int, z, Q):
+        z = _f64(z, (self.total, 3)); Q = _f64(Q, (self.total, 3, 3))
+        _chk(self._lib.ukfb_group_update(self._g, C.c_int(meas_model), _pd(z), _pd(Q)), "ukfb_group_update")
+
+    def cycle(self, dt: float, meas_model: int, z, Q):
+        z = _f64(z, (self.total, 3)); Q = _f64(Q, (self.total, 3, 3))
+        _chk(self._lib.ukfb_group_cycle(self._g, C.c_double(dt), C.c_int(meas_model), _pd(z), _pd(Q)), "ukfb_group_cycle")
+
+    def bind_acceleration_dev(self, acc_devs):
+        _chk(self._lib.ukfb_group_pose_bind_acceleration_dev(self._g, self._ptrs(acc_devs)), "ukfb_group_pose_bind_acceleration_dev")
+
+    def bind_orient_inputs_dev(self, gyro_devs, acc_devs):
+        _chk(self._lib.ukfb_group_orient_bind_inputs_dev(self._g, self._ptrs(gyro_devs), self._ptrs(acc_devs)),
+             "ukfb_group_orient_bind_inputs_dev")
+
+    def cycle_dev(self, dt: float, meas_model: int, z_devs, Q_devs):
+        _chk(self._lib.ukfb_group_cycle_dev(self._g, C.c_double(dt), C.c_int(meas_model), self._ptrs(z_devs), self._ptrs(Q_devs)),
+             "ukfb_group_cycle_dev")
+
+    def cycle_multi_dev(self, cycles: int, dt: float, meas_model: int, z_devs, Q_devs, slots: int, first_slot: int = 0,
+                        in_a_devs=None, in_b_devs=None):
+        _chk(self._lib.ukfb_group_cycle_multi_dev(self._g, C.c_int(cycles), C.c_double(dt), C.c_int(meas_model), C.c_int(slots),
+                                                  C.c_int(first_slot), self._ptrs(in_a_devs), self._ptrs(in_b_devs),
+                                                  self._ptrs(z_devs), self._ptrs(Q_devs)), "ukfb_group_cycle_multi_dev")
+
+    def sync(self):
+        _chk(self._lib.ukfb_group_sync(self._g), "ukfb_group_sync")
+
+    def timer_begin(self):
+        _chk(self._lib.ukfb_group_timer_begin(self._g), "ukfb_group_timer_begin")
+
+    def timer_end(self):
+        """(slowest shard's ms, [ms per shard])"""
+        mx = C.c_float(0)
+        per = (C.c_float * self.n)()
+        _chk(self._lib.ukfb_group_timer_end(self._g, C.byref(mx), per), "ukfb_group_timer_end")
+        return float(mx.value), [float(x) for x in per]
+
+    def gather_means(self, out_devs):
+        """RCCL all-gather of the means: out_devs[r] = device buffer [total][S] (engine precision) on shard r's device."""
+        _chk(self._lib.ukfb_group_gather_means(self._g, self._ptrs(out_devs)), "ukfb_group_gather_means")

@@ -146,7 +146,41 @@ int main()
         bool same = true;
         for (int k = 0; k < NB * 14; ++k) same = same && ma[k] == mb[k];
         for (int k = 0; k < NB * 169; ++k) same = same && ca[k] == cb[k];
-        std::printf("\"batch_cycles_bit_equal\": %s\n", same ? "true" : "false");
+        std::printf("\"batch_cycles_bit_equal\": %s,\n", same ? "true" : "false");
+    }
+
+    // ---------------- ShardedBatchPoseUKF (ukfb_group_*): two shards -- here both on device 0, on a node one per GPU --
+    // against ONE BatchPoseUKF over the same filters: the state must agree bit for bit (filters are independent)
+    {
+        const int NS = 7;   // shards of 4 and 3 filters
+        double ms[NS * 13], cs[NS * 144], am[NS * 3], zz[NS * 3], QQ[NS * 9];
+        x0.toArray(mu);
+        for (int i = 0; i < NS; ++i) {
+            for (int k = 0; k < 13; ++k) ms[i * 13 + k] = mu[k] + ((k < 3 || k > 6) ? 0.01 * i * (k + 1) : 0.0);
+            for (int k = 0; k < 144; ++k) cs[i * 144 + k] = P0.data()[k] * (1.0 + 0.1 * i);
+            am[i * 3 + 0] = 0.2; am[i * 3 + 1] = -0.1 * i; am[i * 3 + 2] = 0.05;
+            zz[i * 3 + 0] = ms[i * 13 + 0] + 0.02; zz[i * 3 + 1] = ms[i * 13 + 1] - 0.01; zz[i * 3 + 2] = ms[i * 13 + 2];
+            for (int k = 0; k < 9; ++k) QQ[i * 9 + k] = (k % 4 == 0) ? 0.0025 : 0.0;
+        }
+        const double acov[9] = {0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.01};
+        BatchPoseUKF single(NS);
+        std::vector<int> devs(2, 0);
+        ShardedBatchPoseUKF sharded(NS, devs);
+        single.initializeFilters(0, NS, ms, cs); sharded.initializeFilters(0, NS, ms, cs);
+        single.setAccelerations(0, NS, am, acov); sharded.setAccelerations(0, NS, am, acov);
+        single.cycle(0.01, UKFB_MEAS_POS3, zz, QQ); sharded.cycle(0.01, UKFB_MEAS_POS3, zz, QQ);
+        single.predictionStep(0.02); sharded.predictionStep(0.02);
+        sharded.sync();
+        double ma[NS * 13], ca[NS * 144], mb[NS * 13], cb[NS * 144];
+        single.getCurrentStates(0, NS, ma, ca); sharded.getCurrentStates(0, NS, mb, cb);
+        bool same = sharded.shards() == 2 && sharded.statusSummary() == 0u;
+        double moved = 0.0;
+        for (int k = 0; k < NS * 13; ++k) { same = same && ma[k] == mb[k]; moved = std::fmax(moved, std::fabs(ma[k] - ms[k])); }
+        for (int k = 0; k < NS * 144; ++k) same = same && ca[k] == cb[k];
+        int64_t f1 = -1, c1 = -1; int d1 = -1;
+        sharded.shard(1, &d1, &f1, &c1);
+        std::printf("\"sharded_bit_equal\": %s, \"sharded_moved\": %.3g, \"sharded_shard1\": [%d, %lld, %lld]\n", same ? "true" : "false", moved, d1,
+                    (long long)f1, (long long)c1);
     }
     std::printf("}\n");
     return 0;

@@ -143,3 +143,26 @@ def test_new_entry_points_reject_a_null_engine(spe):
     assert lib.ukfb_cycle_uniform_q(null, C.c_double(0.01), 0, d9, d9) != 0
     assert lib.ukfb_cycle_uniform_q_dev(null, C.c_double(0.01), 0, null, null) != 0
     assert lib.ukfb_update_uniform_q(null, 0, d9, d9, null) != 0
+
+
+def test_group_entry_points_without_a_gpu(spe):
+    """Device groups (ukfb_group_*): the shard split is the one of sharding.py / bench.py, NULL handles are rejected, and
+    without a HIP device creation fails loudly (no CPU path) -- nothing is launched."""
+    import ctypes as C
+    import torch
+    lib = spe.load_library()
+    for total in (8, 1_048_576, 1_000_003):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                f, c = C.c_int64(-1), C.c_int64(-1)
+                assert lib.ukfb_group_shard_range(C.c_int64(total), world, r, C.byref(f), C.byref(c)) == 0
+                assert (f.value, c.value) == spe.shard_range(total, world, r)
+    assert lib.ukfb_group_shard_range(C.c_int64(8), 2, 2, None, None) != 0
+    null = C.c_void_p(None)
+    assert lib.ukfb_group_size(null) == -1
+    assert lib.ukfb_group_sync(null) != 0 and lib.ukfb_group_cycle_dev(null, C.c_double(0.01), 0, null, null) != 0
+    assert lib.ukfb_group_gather_means(null, null) != 0 and lib.ukfb_group_destroy(null) == 0
+    if not torch.cuda.is_available():
+        with pytest.raises(spe.UkfbError) as ei:
+            spe.UKFGroup(spe.MODEL_POSE, spe.F64, 64, [0, 0])
+        assert "no usable HIP device" in str(ei.value)

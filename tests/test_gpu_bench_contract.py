@@ -97,3 +97,17 @@ def test_two_self_launched_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["filters_per_gpu"] == 8192
     assert d["rccl_ranks"] is None and d["backend"] == "gloo" and d["gather_ms"] is not None and d["status_or"] == 0
     assert d["value"] > 0 and d["parity"]["ok"] is True
+
+
+def test_group_launcher_one_process_two_shards():
+    """`--launcher group`: ONE process drives the shards through ukfb_group_* (the C++ host's multi-GPU shape).  On a 1-GPU
+    box: two shards on device 0 (gather skipped), and a 1-device group whose gather runs through RCCL."""
+    for extra, ranks in (["--gpus", "2", "--group-devices", "0,0"], None), (["--gpus", "1"], 1):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher", "group", "--filters", "32768", "--steps", "8",
+                              "--warmup", "2", "--clock-warmup-seconds", "0.05", "--no-cpu-baseline"] + extra,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        assert d["launcher"] == "group" and d["value"] > 0 and d["status_or"] == 0 and d["config"]["filters"] == 32768
+        assert d["parity"]["ok"] is True and d["rccl_ranks"] == ranks
+        assert (d["gather_ms"] is not None) == (ranks is not None)

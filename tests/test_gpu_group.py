@@ -1,0 +1,93 @@
+"""Device groups through the C-ABI (ukfb_group_*, include/ukf_batch.h): one process, one engine per shard.
+
+Independence basis: every filter of the reference owns its own ukf object (/root/reference/src/UnscentedKalmanFilter.hpp:150),
+so contiguous shards need no collective on the data path; the one exchange is the RCCL all-gather of the means.  A gpurun
+box has ONE GPU: the N > 1 data path is covered by two shards on device 0 (everything but the gather, which RCCL refuses
+for two ranks on one device), the collective by a one-device group (a communicator of one rank)."""
+import numpy as np
+import pytest
+
+from conftest import max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(spe, n, prec):
+    import torch
+    s = spe.synth
+    tdt = torch.float64 if prec == 0 else torch.float32
+    mu, cov = s.pose_initial(n)
+    ring = [s.pose_cycle_inputs(n, k, mu[:, :3]) for k in range(3)]
+    return mu, cov, ring, tdt
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_two_shards_on_one_device_equal_the_unsharded_batch(spe, prec):
+    """Host-array and device-pointer entry points of a 2-shard group against ONE engine over the same filters: bit for bit
+    (same kernels, the same filters in other launches).  The shards are ragged (n odd)."""
+    import torch
+    n = 4099
+    mu, cov, ring, tdt = _inputs(spe, n, prec)
+    acc_cov = 0.01 * np.eye(3)
+    one = spe.BatchPoseUKF(n, precision=prec)
+    grp = spe.UKFGroup(spe.MODEL_POSE, prec, n, [0, 0])
+    assert grp.n == 2 and [(s["first"], s["count"]) for s in grp.shards] == [spe.shard_range(n, 2, r) for r in range(2)]
+    one.initialize(mu, cov); grp.initialize(mu, cov)
+    one.set_acceleration(ring[0][0], acc_cov); grp.set_acceleration(ring[0][0], acc_cov)
+    # host arrays over the whole batch
+    one.cycle(0.01, spe.MEAS_POS3, ring[0][1], ring[0][2]); grp.cycle(0.01, spe.MEAS_POS3, ring[0][1], ring[0][2])
+    one.predict(0.02); grp.predict(0.02)
+    one.update(spe.MEAS_VEL3, ring[1][1], ring[1][2]); grp.update(spe.MEAS_VEL3, ring[1][1], ring[1][2])
+    # device-resident samples: one pointer per shard
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x.reshape(x.shape[0], -1))).to("cuda", tdt)   # noqa: E731
+    a_t, z_t, Q_t = (dev(x) for x in ring[2])
+    cuts = [(s["first"], s["first"] + s["count"]) for s in grp.shards]
+    a_s, z_s, Q_s = ([t[lo:hi].contiguous() for lo, hi in cuts] for t in (a_t, z_t, Q_t))
+    torch.cuda.synchronize()
+    one.bind_acceleration_dev(a_t); one.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t)
+    grp.bind_acceleration_dev(a_s); grp.cycle_dev(0.01, spe.MEAS_POS3, z_s, Q_s)
+    grp.sync(); one.sync()
+    m1, c1, i1 = one.state(); mg, cg, ig = grp.state()
+    assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and i1.all() and ig.all()
+    assert (one.status() == grp.status()).all() and grp.status_summary() == one.status_summary() == 0
+    assert max_abs(m1, mu) > 1e-3
+    # a range that straddles the shard boundary
+    lo = grp.shards[1]["first"] - 5
+    ms, cs, _ = grp.state(lo, 11)
+    assert np.array_equal(ms, m1[lo:lo + 11]) and np.array_equal(cs, c1[lo:lo + 11])
+    # the collective needs one rank per device
+    out = [torch.empty((n, 13), dtype=tdt, device="cuda") for _ in range(2)]
+    with pytest.raises(spe.UkfbError) as ei:
+        grp.gather_means(out)
+    assert "share a device" in str(ei.value)
+    grp.close(); one.close()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_one_device_group_gathers_over_rccl(spe, prec):
+    """A group of one device: the launches are those of a plain engine (bit-equal state), and the gather runs through
+    ncclCommInitAll + ncclAllGather on a communicator of one rank (the RCCL plumbing that N devices use)."""
+    import torch
+    n = 2051
+    mu, cov, ring, tdt = _inputs(spe, n, prec)
+    one = spe.BatchPoseUKF(n, precision=prec)
+    grp = spe.UKFGroup(spe.MODEL_POSE, prec, n, [0])
+    one.initialize(mu, cov); grp.initialize(mu, cov)
+    for e in (one, grp):
+        e.set_acceleration(ring[0][0], 0.01 * np.eye(3))
+        e.cycle(0.01, spe.MEAS_POS3, ring[0][1], ring[0][2])
+    out = [torch.full((n, 13), float("nan"), dtype=tdt, device="cuda")]
+    torch.cuda.synchronize()
+    grp.timer_begin()
+    grp.gather_means(out)
+    ms, per = grp.timer_end()
+    grp.sync()
+    torch.cuda.synchronize()
+    m1, c1, _ = one.state(); mg, cg, _ = grp.state()
+    assert np.array_equal(m1, mg) and np.array_equal(c1, cg)
+    got = out[0].double().cpu().numpy()
+    assert np.array_equal(got, mg) and len(per) == 1 and ms >= 0
+    grp.gather_means(out)      # the communicator and the staging are reused
+    grp.sync()
+    assert np.array_equal(out[0].double().cpu().numpy(), mg)
+    grp.close(); one.close()

@@ -7,8 +7,14 @@
 // installed these types ARE Eigen's (`__has_include(<Eigen/Core>)`); in an image without Eigen (this one) the
 // dependency-free stand-ins below offer the members that code uses, with Eigen's names and semantics, so the
 // same caller text compiles either way.  They carry values only; all filter arithmetic happens in the HIP kernels
-// behind include/ukf_batch.h.  The stand-in stores row-major; every matrix that crosses the C-ABI through data()
-// is symmetric (covariances) or a vector, which makes that indistinguishable from Eigen's column-major default.
+// behind include/ukf_batch.h.  The stand-in stores row-major, Eigen column-major: matrices therefore cross the C-ABI
+// (row-major, lower triangle read -- as Eigen's LLT reads the reference's sigma_) through the explicit (row, column)
+// loops of to_row_major / from_row_major below, never through data().
+//
+// THE REAL-EIGEN BRANCH HAS NEVER BEEN COMPILED in the build image (Eigen is absent there): it is untested.  Two
+// differences to expect: a default-constructed Eigen matrix is uninitialised where the stand-in zero-fills, and Eigen's
+// expression templates may need .eval() where the stand-in returns values.  -DPOSE_ESTIMATION_NO_EIGEN keeps the
+// stand-ins even where Eigen is installed.
 #ifndef POSE_ESTIMATION_TYPES_HPP
 #define POSE_ESTIMATION_TYPES_HPP
 
@@ -206,6 +212,19 @@ typedef pose_estimation::Matrix3d Matrix3d;
 typedef pose_estimation::Quaterniond Quaterniond;
 }  // namespace Eigen
 #endif  // POSE_ESTIMATION_HAS_EIGEN
+
+namespace pose_estimation {
+// matrix <-> the row-major arrays of include/ukf_batch.h, entry by entry: correct for either storage order of Matrix and
+// for a matrix that is not exactly symmetric (the engine reads the LOWER triangle, m(r, c) with c <= r)
+template <typename Scalar, int R, int C> inline void to_row_major(const Matrix<Scalar, R, C>& m, double* out)
+{
+    for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) out[r * C + c] = m(r, c);
+}
+template <typename Scalar, int R, int C> inline void from_row_major(const double* in, Matrix<Scalar, R, C>& m)
+{
+    for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = in[r * C + c];
+}
+}  // namespace pose_estimation
 
 // MTK::SO3<double>(q): the wrapper type the reference converts an Eigen quaternion through
 // (src/pose_with_velocity/BodyStateMeasurement.hpp:17).  With real MTK installed this header is not the one in use.

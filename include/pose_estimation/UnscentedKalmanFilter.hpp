@@ -49,7 +49,9 @@ public:
     {
         double mu[Manifold::STORED];
         initial_state.toArray(mu);
-        check(ukfb_initialize(engine, 0, 1, mu, state_cov.data()), "initializeFilter");
+        double cov_rm[Manifold::DOF * Manifold::DOF];
+        to_row_major(state_cov, cov_rm);
+        check(ukfb_initialize(engine, 0, 1, mu, cov_rm), "initializeFilter");
         initialised = true;
         last_measurement_time.microseconds = 0;
     }
@@ -60,7 +62,9 @@ public:
         if(!initialised)
             return false;
         double mu[Manifold::STORED];
-        check(ukfb_get_state(engine, 0, 1, mu, state_cov.data(), NULL), "getCurrentState");
+        double cov_rm[Manifold::DOF * Manifold::DOF];
+        check(ukfb_get_state(engine, 0, 1, mu, cov_rm, NULL), "getCurrentState");
+        from_row_major(cov_rm, state_cov);
         state.fromArray(mu);
         return true;
     }
@@ -114,7 +118,9 @@ public:
     void setProcessNoiseCovariance(const Covariance& noise_cov)
     {
         process_noise_cov = noise_cov;
-        check(ukfb_set_process_noise(engine, process_noise_cov.data()), "setProcessNoiseCovariance");
+        double noise_rm[Manifold::DOF * Manifold::DOF];
+        to_row_major(process_noise_cov, noise_rm);
+        check(ukfb_set_process_noise(engine, noise_rm), "setProcessNoiseCovariance");
     }
     const base::Time& getLastMeasurementTime() const {return last_measurement_time;}
     void setLastMeasurementTime(const base::Time& last_measurement_time)

@@ -77,7 +77,10 @@ protected:
 
     void latchAcceleration()
     {
-        check(ukfb_pose_set_acceleration(engine, 0, 1, acceleration.mu.data(), acceleration.cov.data()), "acceleration");
+        double mu3[3], cov_rm[9];
+        to_row_major(acceleration.mu, mu3);
+        to_row_major(acceleration.cov, cov_rm);
+        check(ukfb_pose_set_acceleration(engine, 0, 1, mu3, cov_rm), "acceleration");
     }
 
 protected:

@@ -82,3 +82,36 @@ def test_under_torch_distributed_run_every_process_is_a_rank():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["plumbing_only"] is True and d["backend"] == "gloo" and d["config"]["filters_per_gpu"] == 32
+
+
+def test_replayed_counters_are_tied_to_the_binary():
+    """bench.py replays PMC figures from profiles/ only for the kernel, launch size, launch shape AND library hash they were
+    measured on; anything else reports null with the reason in `*_source`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    doc = {"entries": [
+        {"kernel": "ukf_kernel16<f64,pose,cycle>", "filters_per_launch": 1048576, "cycles_per_launch": 1.0, "lib_sha16": "aaaa",
+         "build_head": "h1", "hbm_bytes_per_launch": 1.8e9},
+        {"kernel": "ukf_kernel16<f64,pose,cycle>", "filters_per_launch": 65536, "cycles_per_launch": 1.0, "lib_sha16": "aaaa",
+         "hbm_bytes_per_launch": 1.1e8},
+        {"kernel": "ukf_kernel16<f64,pose,multicycle>", "filters_per_launch": 1048576, "cycles_per_launch": 8.0, "lib_sha16": "aaaa",
+         "hbm_bytes_per_launch": 2.4e9}]}
+    e, exact, src = bench.select_profile_entry(doc, "ukf_kernel16<f64,pose,cycle>", 65536, 1.0, "aaaa")
+    assert e["hbm_bytes_per_launch"] == 1.1e8 and exact and src["matches_running_lib"] and src["lib_sha16"] == "aaaa"
+    e, exact, src = bench.select_profile_entry(doc, "ukf_kernel16<f64,pose,cycle>", 131072, 1.0, "aaaa")
+    assert e is not None and not exact and src["matches_running_lib"]            # another launch size: scaled by the caller
+    e, exact, src = bench.select_profile_entry(doc, "ukf_kernel16<f64,pose,cycle>", 1048576, 1.0, "bbbb")
+    assert e is None and not src["matches_running_lib"] and src["lib_sha16"] == "aaaa" and src["running_lib_sha16"] == "bbbb"
+    e, _, src = bench.select_profile_entry(doc, "ukf_kernel16<f64,pose,multicycle>", 1048576, 1.0, "aaaa")
+    assert e is None and src["lib_sha16"] is None                                # other launch shape: no entry at all
+    e, _, src = bench.select_profile_entry(None, "x", 1, 1.0, "aaaa")
+    assert e is None and not src["matches_running_lib"]
+    # entries written before the hash existed never match
+    e, _, src = bench.select_profile_entry({"entries": [{"kernel": "k", "filters_per_launch": 4}]}, "k", 4, 1.0, "aaaa")
+    assert e is None and src["lib_sha16"] is None
+    # the committed files are readable by the lookup (whatever binary they belong to)
+    for name in ("traffic_latest.json", "pmc_latest.json"):
+        _, _, src = bench.load_profile_entry(name, "ukf_kernel16<f64,pose,cycle>", 1048576, 1.0, "0000")
+        assert src["file"] == "profiles/" + name and src["matches_running_lib"] is False

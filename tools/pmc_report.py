@@ -58,7 +58,8 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "mu
     c = calib[prec]
     hbm = fetch * c["k_read"] + write * c["k_write"]
     cpl = float(bench["roofline"].get("cycles_per_launch", 1.0))   # multi-cycle launches: counters are per launch of cpl cycles
-    traffic.append({"config": name, "kernel": kern, "filters_per_launch": n, "cycles_per_launch": cpl, "precision": prec, "calibration": c,
+    ident = {"lib_sha16": bench.get("lib_sha16"), "build_head": bench.get("build_head")}   # the binary the counters belong to
+    traffic.append({"config": name, **ident, "kernel": kern, "filters_per_launch": n, "cycles_per_launch": cpl, "precision": prec, "calibration": c,
                     "raw": {"FETCH_SIZE_bytes": fetch, "WRITE_SIZE_bytes": write},
                     "hbm_read_bytes_per_launch": fetch * c["k_read"], "hbm_write_bytes_per_launch": write * c["k_write"],
                     "hbm_bytes_per_launch": hbm,
@@ -92,7 +93,7 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "mu
                     + 4.0 * cls["INT64"] + 4.0 * cls["CVT"] + 3.5 * other)
         cls["other(mov,select,compare,dpp mov)"] = other
         cls["dpp_fused_fp32_static"] = dpp_fused
-    e = {"config": name, "kernel": kern, "filters_per_launch": n, "cycles_per_launch": cpl, "precision": prec,
+    e = {"config": name, **ident, "kernel": kern, "filters_per_launch": n, "cycles_per_launch": cpl, "precision": prec,
          "valu_classes_per_wave": cls, "issue_cycles_per_wave_weighted": weighted,
          "valu_issue_frac_weighted_in_pass": (weighted * waves / (1024 * clock_mhz * 1e6 * ns * 1e-9)) if weighted else None,
          "valu_insts_per_wave": valu / waves, "lds_insts_per_wave": lds / waves,

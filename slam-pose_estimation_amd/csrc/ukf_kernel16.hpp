@@ -222,6 +222,9 @@ template <class T> struct MT<OrientM<T>> {
 #ifndef UKFB_ISO_TOL_F32
 #define UKFB_ISO_TOL_F32 1e-4   // | |q|^2 - 1 | up to which an isotropic noise block is not rotated (fp32 engines)
 #endif
+#ifndef UKFB_COMPACT64
+#define UKFB_COMPACT64 0  // 1 (with UKFB_LATE_XM=1): fp64 Pose on the compact 316-scalar LDS slice (Layout16::COMPACT), 4 wavefronts per SIMD -- measured and rejected; 0: the plain 396-scalar slice
+#endif
 #ifndef UKFB_F32_TRIM
 #define UKFB_F32_TRIM 1   // 0: the fp32 Pose slice as before round 2's last trim (424 floats, 21 workgroups per CU): -2.7 %
 #endif
@@ -247,21 +250,46 @@ template <class T, class M> struct Layout16 {
     static constexpr int LC = 0;                            // D*LS : unscaled factor columns
     // delta table rows 0..N-1 alias the factor (dead once every lane holds its column); its zero row lies behind it
     static constexpr int TNL = (D * LS > N * ST) ? (D * LS - N * ST) : 0;
-    static constexpr int PKS = al(TNL + (N + 1) * ST);      // PKP  : packed covariance staging (survives the prediction)
-    static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor.  Where !LAF_ROW_D its zero row D
-                                                            // (read by the cross lanes in their last trip) is not stored: it aliases the
-                                                            // mean staging behind it - finite values that meet the table's exact-zero row
     static constexpr bool LAF_ROW_D = !(M::MODEL == 0 && (sizeof(T) == 8 || UKFB_F32_TRIM));   // only the Pose slices need the trim
     // fp32 Pose: the small regions packed to 8-byte instead of 16-byte boundaries bring the slice to 400 floats = 6400 B =
     // 5 allocation granules: 24 workgroups per CU = 6 wavefronts per SIMD (77 VGPRs allow it)
     static constexpr int alm(int x) { return (M::MODEL == 0 && sizeof(T) == 4 && UKFB_F32_TRIM) ? (x + 1) / 2 * 2 : al(x); }
-    static constexpr int MISC = LAF + al((D + (LAF_ROW_D ? 1 : 0)) * ST);
+    // COMPACT (fp64 Pose, round 3): the slice at 316 scalars = 10 112 B per wavefront, under the 10 240 B that 16 one-wave
+    // workgroups per CU = FOUR wavefronts per SIMD need (LDS allocation granule 1 280 B).  Against the plain layout (396):
+    //  * the staged covariance is split: its affine triangle (rows / columns >= NL, 21 entries, the block the prediction
+    //    updates in place) in AFF, the nonlinear triangle and the cross block (57 entries) in REST -- and the scaled affine
+    //    factor rows LAF (72) ALIAS REST: between the prediction's row loads and its tile stores those 57 entries are dead
+    //    (a filter that does not commit keeps them: its LAF rows go to the sink);
+    //  * the rotation matrix of the mean lives in the head of the factor region (free once every lane holds its column and
+    //    the transposition buffer is done: it is written in p_delta_e, not before the factorisation);
+    //  * the store sink IS the shaped-noise region (the only sink store between that table's fill and its fetch is the
+    //    fill's own, which goes to the table's spare slot).
+    static constexpr bool COMPACT = (M::MODEL == 0 && sizeof(T) == 8 && UKFB_COMPACT64 != 0);
+    static constexpr int NAFF = (D - NL) * (D - NL + 1) / 2, NTRI = NL * (NL + 1) / 2, NREST = PK - NAFF;
+    static constexpr int UEND = al(TNL + (N + 1) * ST);     // end of the factor / delta-table region
+    static constexpr int PKS = UEND;                        // plain: PKP scalars, packed lower triangle (survives the prediction)
+    static constexpr int AFF = UEND;                        // compact: affine triangle, local packed order
+    static constexpr int REST = AFF + al(NAFF);             // compact: nonlinear triangle (local packed order), then the cross block [r - NL][c]
+    static constexpr int LAF = COMPACT ? REST : (PKS + PKP);   // (D+1)*ST : row l = scaled affine rows of column l of the factor.  Where !LAF_ROW_D its zero row D
+                                                            // (read by the cross lanes in their last trip) is not stored: it aliases the
+                                                            // mean staging behind it - finite values that meet the table's exact-zero row
+    static constexpr int LAF_SZ = al((D + (LAF_ROW_D ? 1 : 0)) * ST);
+    static_assert(!COMPACT || (LAF_SZ >= NREST && !LAF_ROW_D), "compact layout: LAF covers REST and is followed by the mean staging");
+    static constexpr int MISC = LAF + LAF_SZ;
     static constexpr int MUS = MISC;                        // S  : mean staging
-    static constexpr int ROT = MUS + alm(S);                // 9  : rotation matrix of the mean
-    static constexpr int ZQ = ROT + alm(9);                 // 12 : z (3) + Q (9)
+    static constexpr int ROT = COMPACT ? LC : (MUS + alm(S));   // 9  : rotation matrix of the mean
+    static constexpr int ZQ = COMPACT ? (MUS + alm(S)) : (ROT + alm(9));   // 12 : z (3) + Q (9)
     static constexpr int NSH = ZQ + 12;                     // 21 : shaped process noise of the nonlinear block
-    static constexpr int DUM = NSH + alm(21);               // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
-    static constexpr int PF_RAW = DUM + alm(S);
+    static constexpr int NSH_SINK = COMPACT ? (NSH + 21) : (NSH + alm(21));   // where the fill of NSH sends its idle lanes
+    static constexpr int DUM = COMPACT ? NSH : (NSH + alm(21));   // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
+    static constexpr int PF_RAW = COMPACT ? (NSH + alm(21)) : (DUM + alm(S));
+    static_assert(!COMPACT || (alm(21) > 21 && alm(21) >= S && 10 <= TNL), "compact layout: sink and rotation matrix fit their hosts");
+    // LDS index (from the slice base) of covariance entry (r, c), c <= r
+    __host__ __device__ static constexpr int cv(int r, int c) {
+        if (!COMPACT) return PKS + r * (r + 1) / 2 + c;
+        return (r < NL) ? (REST + r * (r + 1) / 2 + c)
+                        : ((c < NL) ? (REST + NTRI + (r - NL) * NL + c) : (AFF + (r - NL) * (r - NL + 1) / 2 + (c - NL)));
+    }
     // Workgroups per CU follow the LDS allocation granule of 1280 B (measured, tools/lds_granule.hip; the occupancy API
     // assumes 512 B): the fp64 Pose slice must stay <= 12800 B per workgroup for 12 workgroups = 3 wavefronts per SIMD
     // (it was 13120 B = 11 workgroups per CU until round 2).
@@ -296,9 +324,11 @@ template <class T, class M> struct CovTab {
     static constexpr int RD_PR = 0, RD_PC = 1, RD_WS = 2, RD_NZ = 4, RD_ANZ = 5;   // rd row (RD_WS: one or two dwords)
     static constexpr int WR_TILE = 0, WR_AFF = TR * TC, WR_AFF_RD = TR * TC + AEL;  // wr row
     static_assert(RD_ANZ + AEL <= NRD && WR_AFF_RD + AEL <= NWR, "covariance lane tables");
+    static constexpr int EPLT = (LY::PK + 15) / 16;
     struct Tabs {
         uint32_t rd[16][NRD];
         uint32_t wr[17][NWR];
+        uint32_t stage[16][EPLT];   // LDS byte offset of packed entry l + 16 t (entries past the triangle: the sink)
     };
     static constexpr int tri_r(int e) {
         int r = 0;
@@ -328,7 +358,7 @@ template <class T, class M> struct CovTab {
                 for (int j2 = 0; j2 < TC; ++j2) {
                     const int r = R0 + i2, c = C0 + j2;
                     const bool w = writer && r < D && c <= r;
-                    t.wr[l][WR_TILE + i2 * TC + j2] = w ? uint32_t((LY::PKS + r * (r + 1) / 2 + c) * SZ) : sink;
+                    t.wr[l][WR_TILE + i2 * TC + j2] = w ? uint32_t(LY::cv(r, c) * SZ) : sink;
                 }
             for (int k = 0; k < AEL; ++k) {
                 const int e = l + 16 * k;
@@ -336,12 +366,18 @@ template <class T, class M> struct CovTab {
                 const int rr = v ? tri_r(e) : 0, cc = v ? (e - rr * (rr + 1) / 2) : 0;
                 const int ar = NL + rr, ac = NL + cc;
                 t.rd[l][RD_ANZ + k] = uint32_t((ar * D + ac) * SZ);
-                t.wr[l][WR_AFF + k] = v ? uint32_t((LY::PKS + ar * (ar + 1) / 2 + ac) * SZ) : sink;
-                t.wr[l][WR_AFF_RD + k] = uint32_t((LY::PKS + ar * (ar + 1) / 2 + ac) * SZ);
+                t.wr[l][WR_AFF + k] = v ? uint32_t(LY::cv(ar, ac) * SZ) : sink;
+                t.wr[l][WR_AFF_RD + k] = uint32_t(LY::cv(ar, ac) * SZ);
             }
         }
+        for (int l = 0; l < 16; ++l)
+            for (int k = 0; k < EPLT; ++k) {
+                const int e = l + 16 * k;
+                const int r = tri_r(e), c = e - r * (r + 1) / 2;
+                t.stage[l][k] = (e < LY::PK) ? uint32_t(LY::cv(r, c) * SZ) : sink;
+            }
         for (int k = 0; k < NWR; ++k) t.wr[16][k] = sink;
-        for (int k = 0; k < AEL; ++k) t.wr[16][WR_AFF_RD + k] = uint32_t((LY::PKS + NL * (NL + 1) / 2 + NL) * SZ);
+        for (int k = 0; k < AEL; ++k) t.wr[16][WR_AFF_RD + k] = uint32_t(LY::cv(NL, NL) * SZ);
         return t;
     }
     static constexpr Tabs tabs = make();
@@ -443,6 +479,20 @@ template <class T, int D> UKFB_DEV void load_row(const T* PKS, int l, T (&row)[D
     for (int j = 0; j < D; ++j) row[j] = p[j];
 }
 
+// The same from the compact slice (Layout16::COMPACT): columns < NL of row l come from the nonlinear triangle or the cross
+// block, columns >= NL from the affine triangle -- two base addresses, immediate offsets.  What lies beyond the diagonal is
+// again whatever follows (staged covariance entries, finite).
+template <class T, class LY> UKFB_DEV void load_row_compact(const T* base, int l, T (&row)[LY::D]) {
+    constexpr int D = LY::D, NL = LY::NL;
+    const int lr = (l < D) ? l : (D - 1);
+    const int la = (lr < NL) ? 0 : (lr - NL);
+    const T* pa = base + ((lr < NL) ? (LY::REST + lr * (lr + 1) / 2) : (LY::REST + LY::NTRI + la * NL));
+    const T* pb = base + LY::AFF + la * (la + 1) / 2;
+    static_assert((NL - 1) * NL / 2 + NL - 1 < LY::NREST && (D - NL - 1) * (D - NL) / 2 + D - NL - 1 < LY::NAFF, "row reads stay inside the staging");
+#pragma unroll
+    for (int j = 0; j < D; ++j) row[j] = (j < NL) ? pa[j] : pb[j - NL];
+}
+
 // scaled column l of the factor (the stored column already has zeros above the diagonal);
 // lanes without a column (l >= D) get zeros through w = 0
 template <class T, int D, int LS> UKFB_DEV void load_column(const T* Lc, int l, T rs, T (&col)[D]) {
@@ -505,13 +555,14 @@ template <class T> UKFB_DEV void process_fast(OrientM<T>*, T (&x)[14], const Pro
 }
 
 // sigma pair mu [+] (+col), mu [+] (-col): one exp serves both points, exp(-v) = conj(exp(v))
-template <class T, class M>
+// (QUAT_ONLY_MINUS: the Euclidean components of the minus point are left for the caller to form later)
+template <class T, class M, bool QUAT_ONLY_MINUS = false>
 UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], T (&xp)[M::S], T (&xm)[M::S]) {
     constexpr int Q = MT<M>::Q, RT = MT<M>::RT, S = M::S;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (s < Q) { xp[s] = mu[s] + col[s]; xm[s] = mu[s] - col[s]; }
-        else if (s >= Q + 4) { xp[s] = mu[s] + col[s - 1]; xm[s] = mu[s] - col[s - 1]; }
+        if (s < Q) { xp[s] = mu[s] + col[s]; if constexpr (!QUAT_ONLY_MINUS) xm[s] = mu[s] - col[s]; }
+        else if (s >= Q + 4) { xp[s] = mu[s] + col[s - 1]; if constexpr (!QUAT_ONLY_MINUS) xm[s] = mu[s] - col[s - 1]; }
     }
     const T q[4] = {mu[Q], mu[Q + 1], mu[Q + 2], mu[Q + 3]};
     const T v[3] = {col[RT], col[RT + 1], col[RT + 2]};
@@ -594,6 +645,9 @@ constexpr unsigned long long tri_cols(int first) {
 #ifndef UKFB_SF_PROC
 #define UKFB_SF_PROC 1
 #endif
+#ifndef UKFB_LATE_XM
+#define UKFB_LATE_XM 0
+#endif
 #ifndef UKFB_MEAN1_TRANSPOSE
 #define UKFB_MEAN1_TRANSPOSE 1
 #endif
@@ -604,6 +658,14 @@ constexpr unsigned long long tri_cols(int first) {
 #define UKFB_W32 5
 #endif
 template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W64 : UKFB_W32; }
+// wavefronts per SIMD the register allocator must leave room for, per instantiation.  The fp64 Pose kernels on the compact
+// slice fit FOUR (128 VGPRs, no spill: tools/check_resources.py) -- except the multi-cycle kernel, whose input prefetch
+// keeps it at three.
+template <class T, class M, bool MULTI> constexpr int waves16() {
+    if (sizeof(T) == 4) return MULTI ? 4 : min_waves16<T>();
+    if (Layout16<T, M>::COMPACT && UKFB_LATE_XM != 0) return MULTI ? 3 : 4;
+    return min_waves16<T>();
+}
 
 // Element idx of an array entered through a scalar base: the byte offset is formed in 32 bits, so that the load / store takes
 // the base as its scalar operand and the offset as its 32-bit vector operand (base[idx] would widen idx first and add in 64 bits)
@@ -634,7 +696,7 @@ template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
 // lane and stream (8 v_mad_u64_u32, 2 v_mul_lo_u32, 7 v_lshl_add_u64 per wavefront; 45 instructions fewer in all).  Measured:
 // +0.7 % fp64, nothing in fp32 -- the prologue is not where a wavefront's time goes.
 template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false>
-__global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves16<T>()) ukf_kernel16(const KArgs<T> a) {
+__global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(const KArgs<T> a) {
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
     static_assert(!INDIRECT || (DO_PREDICT && DO_UPDATE && !MULTI), "indirect launches run the single fused cycle");
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
@@ -759,6 +821,12 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
         const int e = l + G * t;
         cov_l[t] = *at(static_cast<const T*>(cov_p), fc * PK + IDX((e < PK) ? e : (PK - 1)));
     }
+    uint32_t stage_off[EPL];   // compact slice: where packed entry l + 16 t is staged (lane table, requested with the state)
+    if constexpr (LY::COMPACT) {
+        static_assert(CovTab<T, M>::EPLT == EPL, "staging table");
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) stage_off[t] = CovTab<T, M>::tabs.stage[l][t];
+    }
     const T mu_l = *at(static_cast<const T*>(mu_p), fc * S + IDX((l < S) ? l : (S - 1)));
     ProcIn<T> pin;
     // per-call inputs of one input slot (single-cycle launches: slot 0 = the arrays themselves)
@@ -805,10 +873,15 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
 
     UKFB_MARK("stage");
     // ---- stage the filter in LDS: packed covariance, mean, measurement
+    if constexpr (LY::COMPACT) {   // split staging (affine triangle | nonlinear triangle + cross block): offsets from the lane table
 #pragma unroll
-    for (int t = 0; t < EPL; ++t) {
-        const int e = l + G * t;
-        PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = cov_l[t];
+        for (int t = 0; t < EPL; ++t) *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + stage_off[t]) = cov_l[t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int e = l + G * t;
+            PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = cov_l[t];
+        }
     }
     MUS[(l < S) ? l : (LY::DUM - LY::MUS)] = mu_l;
     const bool live = fvalid && (init_b != 0);
@@ -936,14 +1009,19 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             // stored index of a nonlinear Euclidean tangent component t (t outside [RT, RT + 3))
             constexpr auto st_of = [](int t) constexpr { return t < MT<M>::RT ? t : t + 1; };
             T xp[S], xm[S], ref[S];
+            constexpr bool LATE_XM = (sizeof(T) == 8) && (UKFB_LATE_XM != 0);
+            T rs_keep = T(0);
             bool ok;
             bool noise_plain = false;   // wave-uniform: the process noise needs no rotation (see below)
-            T qn2;   // |q|^2 of the mean's orientation = norm of every conj(a) * b between sigma-point orientations
+            bool need_rot = false;      // wave-uniform: the rotated noise blocks are evaluated, they need the mean's rotation matrix
+            T qn2 = T(1);   // |q|^2 of the mean's orientation = norm of every conj(a) * b between sigma-point orientations
             {
                 T mu_r[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
-                qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
+                // (the late-minus-point variant takes it after the process models, from the staging: two registers less at the peak)
+                if constexpr (!(LATE_XM && M::MODEL == 0))
+                    qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
                 // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose acceleration branch does
                 // not rotate its noise (wave-uniform skip).  An isotropic block is its own rotation (R s I R^T = s I R R^T): with
                 // the launch-wide flag set by the host and unit orientation quaternions (|q|^2 within 1e-9 of 1 on every lane,
@@ -953,19 +1031,23 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 // headline 0.6 % through code placement alone, same-box A/B)
                 if constexpr (M::MODEL != 0)
                     noise_plain = a.noise_iso != 0 && wave_all(m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(UKFB_ISO_TOL_F32)));
-                if (!noise_plain && (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc)))) {
-                    T q[4], rot[9];
-                    M::orientation(mu_r, q);
-                    quat_to_matrix(q, rot);
-                    T* dst = (l == 0) ? ROT : DUMP;
+                need_rot = !noise_plain && (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc)));
+                if constexpr (!LY::COMPACT) {
+                    if (need_rot) {
+                        T q[4], rot[9];
+                        M::orientation(mu_r, q);
+                        quat_to_matrix(q, rot);
+                        T* dst = (l == 0) ? ROT : DUMP;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) dst[k] = rot[k];
+                        for (int k = 0; k < 9; ++k) dst[k] = rot[k];
+                    }
                 }
                 T rs;
                 {
                     T arow[D];
                     UKFB_MARK("p_chol_row");
-                    load_row<T, D>(PKS, l, arow);
+                    if constexpr (LY::COMPACT) load_row_compact<T, LY>(base, l, arow);
+                    else load_row<T, D>(PKS, l, arow);
                     UKFB_MARK("p_chol_fact");
                     UKFB_PRIO(UKFB_CHOL_PRIO);
                     rs = chol16<T, D, LS>(arow, Lc, l, ok);
@@ -973,25 +1055,55 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                     wsync();
                 }
                 UKFB_MARK("p_sigma");
+                rs_keep = rs;
                 T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
                 {   // affine rows of this lane's column, scaled by the model's diagonal factor, for the cross block;
                     // lanes without a column hold zeros: they fill LAF's zero row, or go to the sink where that row is
                     // not stored (Layout16::LAF_ROW_D)
-                    T* lrow = LY::LAF_ROW_D ? (LAF + ((l < D) ? l : D) * ST) : ((l < D) ? (LAF + l * ST) : DUMP);
+                    // (compact slice: LAF aliases staged covariance entries that a filter whose prediction is not committed
+                    // must keep -- its rows go to the sink, its cross lanes then read finite leftovers and store nothing)
+                    T* lrow = LY::LAF_ROW_D ? (LAF + ((l < D) ? l : D) * ST)
+                                            : (((l < D) && (!LY::COMPACT || (do_p && ok))) ? (LAF + l * ST) : DUMP);
 #pragma unroll
                     for (int c = NL; c < D; ++c) lrow[c - NL] = (M::MODEL == 0) ? col[c] : col[c] * MT<M>::aff_scale(c, pin);
                 }
-                sigma_pair<T, M>(mu_r, col, xp, xm);
+                sigma_pair<T, M, LATE_XM>(mu_r, col, xp, xm);
             }
             UKFB_MARK("p_process");
             const bool pc = do_p && ok;            // this filter's predict will be committed
             sfence();
             process_fast((M*)nullptr, xp, pin);    // lanes >= D carry the centre point (their column is zero)
             if constexpr (UKFB_SF_PROC != 0) sfence();
+            if constexpr (LATE_XM) {
+                // fp64: the Euclidean part of the minus point is formed only now, from the staged mean and the factor column
+                // (both still in LDS): thirteen values less to hold through the first process model, where the register
+                // demand of the whole kernel peaks (tools/isa_liveness.py); its quaternion came with the plus point's
+                const int lc = (l < D) ? l : (D - 1);
+                const T w = (l < D) ? rs_keep : T(0);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s < Q) xm[s] = fma(-Lc[lc * LS + s], w, MUS[s]);
+                    else if (s >= Q + 4) xm[s] = fma(-Lc[lc * LS + s - 1], w, MUS[s]);
+                }
+            }
+            if constexpr (LATE_XM) {
+                // ... and the affine part of the new mean, which IS the propagated centre (see p_mean1), leaves the centre
+                // lane's registers right away
+                T* dstc0 = (pc && has_ctr) ? MUS : DUMP;
+                T* dstc = dstc0;
+                asm volatile("" : "+v"(dstc));
+                // (after every lane has read the old mean for its minus point: one wavefront, LDS in program order)
+#pragma unroll
+                for (int s = NL + 1; s < S; ++s) dstc[s] = xp[s];
+            }
             process_fast((M*)nullptr, xm, pin);
             sfence();
             UKFB_MARK("p_mean1");
+            if constexpr (LATE_XM && M::MODEL == 0) {   // |q|^2 of the OLD mean (its quaternion is still staged)
+                const T q0 = MUS[Q], q1 = MUS[Q + 1], q2 = MUS[Q + 2], q3 = MUS[Q + 3];
+                qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+            }
             // Propagated centre point (lane D): every lane starts the mean from it.  The affine components
             // (tangent >= NL) of the sigma points are centre +- scale * L[c][l] exactly, so their mean IS the centre
             // (ukfom's iteration finds a correction at rounding level) and their deltas are the signed factor rows.
@@ -1068,6 +1180,19 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             UKFB_MARK("p_delta_e");
             // Euclidean part of the mean is final: write those delta columns now and drop the registers.
             wsync();  // every lane is done with the transposition buffer (it aliases the table)
+            if constexpr (LY::COMPACT) {
+                // compact slice: the rotation matrix of the (old) mean goes to the head of the factor region, which nothing
+                // reads any more (columns loaded, transposition done; the table starts behind it) -- the quaternion is still
+                // the old one in the mean staging (the new one follows in p_delta_r)
+                if (need_rot) {
+                    const T q[4] = {MUS[Q], MUS[Q + 1], MUS[Q + 2], MUS[Q + 3]};
+                    T rot[9];
+                    quat_to_matrix(q, rot);
+                    T* dst = (l == 0) ? ROT : DUMP;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dst[k] = rot[k];
+                }
+            }
             // rows 0..D (lane l <= D): U_l, the centre lane's row scaled by sqrt(1/2) (its U is delta_0);
             // rows D+1..N: W_l, where the centre lane's W = 0 is the table's zero row
             T* const rowu = has_p ? (TAB + l * ST) : DUMP;
@@ -1087,7 +1212,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 T* dstc = (pc && has_ctr) ? MUS : DUMP;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if (s >= NL + 1) dstc[s] = xp[s];
+                    if (s >= NL + 1) { if constexpr (!LATE_XM) dstc[s] = xp[s]; }
                     else if (s < Q || s >= Q + 4) dst[s] = ref[s];
                 }
             }
@@ -1237,7 +1362,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                     for (int t = 0; t < 2; ++t) {
                         const bool v = l + G * t < NL * (NL + 1) / 2;
                         const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
-                        NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                        NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
                     }
                     const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
                     const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
@@ -1495,13 +1620,13 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                         innov[k] = zin[k] - MUS[sb + k];
                         const int tk = tb + k;
                         const int hi = la > tk ? la : tk, lo = la > tk ? tk : la;
-                        cx[k] = PKS[hi * (hi + 1) / 2 + lo];
+                        cx[k] = base[LY::cv(hi, lo)];
                     }
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int c = 0; c <= r; ++c) {
-                            const T sp = PKS[(tb + r) * (tb + r + 1) / 2 + tb + c];
+                            const T sp = base[LY::cv(tb + r, tb + c)];
                             Sm[r * 3 + c] = sp + ZQ[3 + r * 3 + c];
                             if (c < r) Sm[c * 3 + r] = sp + ZQ[3 + c * 3 + r];
                         }
@@ -1519,7 +1644,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                     keep(m0);
                     innov[k] = used[k] ? (zin[k] - m0) : T(0);
                     const int hi = la > ti[k] ? la : ti[k], lo = la > ti[k] ? ti[k] : la;
-                    T sx = PKS[hi * (hi + 1) / 2 + lo];
+                    T sx = base[LY::cv(hi, lo)];
                     keep(sx);
                     cx[k] = used[k] ? sx : T(0);
                 }
@@ -1529,7 +1654,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                     for (int c = 0; c < 3; ++c) {
                         const int hi = ti[r] > ti[c] ? ti[r] : ti[c], lo = ti[r] > ti[c] ? ti[c] : ti[r];
                         const T pad = (r == c) ? T(1) : T(0);
-                        T sp = PKS[hi * (hi + 1) / 2 + lo], sq = ZQ[3 + r * 3 + c];
+                        T sp = base[LY::cv(hi, lo)], sq = ZQ[3 + r * 3 + c];
                         keep(sp);
                         keep(sq);
                         Sm[r * 3 + c] = (used[r] && used[c]) ? (sp + sq) : pad;
@@ -1550,7 +1675,8 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 T rs;
                 {
                     T arow[D];
-                    load_row<T, D>(PKS, l, arow);
+                    if constexpr (LY::COMPACT) load_row_compact<T, LY>(base, l, arow);
+                    else load_row<T, D>(PKS, l, arow);
                     // Only the first ZCOLS columns of the factor move the measurement.  An indefinite Sigma whose
                     // first ZCOLS pivots are positive is caught by the complete factorisation of Sigma' below
                     // (Sigma' <= Sigma), with the same status bit.
@@ -1725,7 +1851,8 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
             T rs2;
             {
                 T arow2[D];
-                load_row<T, D>(PKS, l, arow2);
+                if constexpr (LY::COMPACT) load_row_compact<T, LY>(base, l, arow2);
+                else load_row<T, D>(PKS, l, arow2);
                 const T nks[3] = {-KSr[0], -KSr[1], -KSr[2]};
                 dpp_hazard_fence(Kr[0]);
                 dpp_hazard_fence(Kr[1]);
@@ -1817,16 +1944,36 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 // rowbase(l)) > c, i.e. earlier in this descending loop.  The last row has nothing beyond its diagonal.
                 // (The stores of one lane never alias each other, so the compiler would be free to reorder or pair
                 // them; the order that matters is between LANES, hence the compiler fence after every store.)
-                T* rowdst = wl ? (PKS + l * (l + 1) / 2) : DUMP;
+                if constexpr (LY::COMPACT) {
+                    // The compact slice keeps two triangles (nonlinear rows / columns < NL; affine >= NL) and the cross block
+                    // apart.  The argument above holds inside each triangle with its local column index; the cross rows
+                    // have no entry beyond a diagonal at all.  Columns < NL first, then columns >= NL (rows < NL: the sink).
+                    constexpr int NL = LY::NL;
+                    const int la = (l < NL) ? 0 : (l - NL);
+                    T* dsta = wl ? (base + ((l < NL) ? (LY::REST + l * (l + 1) / 2) : (LY::REST + LY::NTRI + la * NL))) : DUMP;
+                    T* dstb = (wl && l >= NL) ? (base + LY::AFF + la * (la + 1) / 2) : DUMP;
 #pragma unroll
-                for (int b = D - 1; b >= 0; --b) {
-                    rowdst[b] = srow2[b];
-                    asm volatile("" ::: "memory");
+                    for (int b = NL - 1; b >= 0; --b) {
+                        dsta[b] = srow2[b];
+                        asm volatile("" ::: "memory");
+                    }
+#pragma unroll
+                    for (int b = D - 1; b >= NL; --b) {
+                        dstb[b - NL] = srow2[b];
+                        asm volatile("" ::: "memory");
+                    }
+                } else {
+                    T* rowdst = wl ? (PKS + l * (l + 1) / 2) : DUMP;
+#pragma unroll
+                    for (int b = D - 1; b >= 0; --b) {
+                        rowdst[b] = srow2[b];
+                        asm volatile("" ::: "memory");
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int hi = l > RT + k ? l : RT + k, lo = l > RT + k ? RT + k : l;
-                    PKS[wl ? (hi * (hi + 1) / 2 + lo) : (LY::DUM - LY::PKS)] = cr[k];
+                    base[wl ? LY::cv(hi, lo) : LY::DUM] = cr[k];
                 }
                 asm volatile("" ::: "memory");
                 const bool w0 = u_commit && l == 0;
@@ -1834,7 +1981,7 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int c = 0; c <= r; ++c)
-                        PKS[w0 ? ((RT + r) * (RT + r + 1) / 2 + RT + c) : (LY::DUM - LY::PKS)] = rr[r * (r + 1) / 2 + c];
+                        base[w0 ? LY::cv(RT + r, RT + c) : LY::DUM] = rr[r * (r + 1) / 2 + c];
             }
             sfence();
             UKFB_MARK("u_mean");
@@ -1889,7 +2036,12 @@ __global__ void __launch_bounds__(64, (MULTI && sizeof(T) == 4) ? 4 : min_waves1
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const int e = l + G * t;
-            if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = PKS[e];
+            if constexpr (LY::COMPACT) {
+                const uint32_t off = CovTab<T, M>::tabs.stage[l][t];
+                if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + off);
+            } else {
+                if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = PKS[e];
+            }
         }
         if (l < S) *at(mu_c, fcc * S + IDX(l)) = MUS[l];
     }

@@ -109,7 +109,9 @@ static int64_t split_max_filters() {
 template <class T, class M> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
     constexpr int FPW = 4;
     const int64_t grid = (args.n + FPW - 1) / FPW;
-    const int lds = FPW * lds_bytes_per_filter16<T, M>();
+    // (UKFB_LDS_PAD_BYTES in the environment requests that much more dynamic LDS per workgroup: occupancy experiments only)
+    static const int lds_pad = [] { const char* s = std::getenv("UKFB_LDS_PAD_BYTES"); return s ? std::atoi(s) : 0; }();
+    const int lds = FPW * lds_bytes_per_filter16<T, M>() + lds_pad;
     const bool multi = r.cycles > 0;   // ukfb_cycle_multi_dev: fused cycles only (checked by the caller)
     const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : "cycle") : "predict") : "update");
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +

@@ -92,6 +92,11 @@ def parse():
     ap.add_argument("--cpu-sample-seconds", type=float, default=9.0,
                     help="CPU time of the three all-core samples together (the thread-ladder probes and the one-core sample come on top)")
     ap.add_argument("--parity-sample", type=int, default=4096)
+    ap.add_argument("--inputs", choices=["ring", "tracking"], default="ring",
+                    help="ring (default, the figures of every round): the steps cycle through 4 fixed input sets drawn around the "
+                         "INITIAL position.  tracking (pose / pose-cv): every step's position fix is regenerated on the device as "
+                         "current mean position + that step's noise (one elementwise kernel per step on the engine's stream, inside "
+                         "the timed region), i.e. the innovation stays at noise level however long the run is (SURVEY 8(d))")
     ap.add_argument("--launcher", choices=["procs", "group"], default="procs",
                     help="procs (default, the measured contract): one process per GPU, torch.distributed over RCCL. group: ONE "
                          "process drives all N GPUs through the C-ABI device group (ukfb_group_*: one engine and stream per "
@@ -281,6 +286,8 @@ def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):
         m_o, c_o = (f32(mu), f32(cov)) if start is None else (start[0], start[1])
         for k in range(k0, cycles):
             acc, z, Q, models = ring[k % N_RING]
+            if args.inputs == "tracking":   # the fix of this step: the mean position BEFORE the step + the step's noise
+                z = f32(m_o[:, :3] + f32(z - mu[:, :3]))
             m_o, c_o, _ = capi.pose_predict(m_o, c_o, R, None if args.workload == "pose-cv" else f32(acc), acc_cov, DT,
                                             prec=oprec, threads=threads)
             m_o, c_o, _ = capi.pose_update(m_o, c_o, models, f32(z), f32(Q), prec=oprec, threads=threads)
@@ -395,6 +402,9 @@ def run_rank(args):
     first, per = spe.shard_range(total, world, rank)
     orient = args.workload == "orient"
     S = 14 if orient else 13
+    tracking = args.inputs == "tracking"
+    if tracking and (args.workload not in ("pose", "pose-cv") or args.cycles_per_launch != 1):
+        raise SystemExit("--inputs tracking applies to --workload pose / pose-cv with one cycle per launch")
 
     def fence():
         if dist is not None:
@@ -439,7 +449,9 @@ def run_rank(args):
                                       split_streams=args.split_streams)
         eng.set_process_noise(sy.orient_process_noise())
     else:
-        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private",
+        # (tracking inputs: the engine runs on torch's current stream, the per-step generator kernel is a torch op ordered with it)
+        eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter,
+                               stream=None if tracking else "private",
                                bucket_models=args.bucket_models, split_streams=args.split_streams)
     # input rings [N_RING][filters][..], contiguous (a multi-cycle launch addresses its slots inside them); *_d: the slots
     acc_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
@@ -471,6 +483,8 @@ def run_rank(args):
                     z = spe.synth.pose_measurement_for_model(mu, models, z - mu[:, :3])
                     m_d[k][lo:hi] = torch.from_numpy(models).to(dev)
             acc_d[k][lo:hi] = torch.from_numpy(acc).to(dev, tdtype)
+            if tracking:
+                z = z - mu[:, :3]      # the noise alone; the position it is added to is the filter's own, step by step
             z_d[k][lo:hi] = torch.from_numpy(z).to(dev, tdtype)
             Q_d[k][lo:hi] = torch.from_numpy(Q.reshape(-1, 9)).to(dev, tdtype)
     if not orient:
@@ -490,7 +504,11 @@ def run_rank(args):
         else:
             if not cv:
                 eng.bind_acceleration_dev(acc_d[r])
-            eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r], meas_model_dev=m_d[r] if m_d else None)
+            if tracking:   # z = current mean position + this step's noise (z_ring holds the noise in this mode)
+                torch.add(mu_view[:, :3], z_d[r], out=z_track)
+                eng.cycle_dev(DT, spe.MEAS_POS3, z_track, Q_d[r])
+            else:
+                eng.cycle_dev(DT, spe.MEAS_POS3, z_d[r], Q_d[r], meas_model_dev=m_d[r] if m_d else None)
         done[0] += 1
 
     def run_cycles(k):
@@ -532,6 +550,7 @@ def run_rank(args):
     ts_ = "<f8" if prec == spe.F64 else "<f4"
     mu_view = torch.as_tensor(_DevArray(mu_ptr, (per, S), ts_), device=dev)
     cov_view = torch.as_tensor(_DevArray(cov_ptr, (per, eng.PK), ts_), device=dev)
+    z_track = torch.empty((per, 3), dtype=tdtype, device=dev) if tracking else None
     if args.clock_warmup_seconds > 0:
         init_state = (mu_view.clone(), cov_view.clone())
         torch.cuda.synchronize()
@@ -612,7 +631,7 @@ def run_rank(args):
         time.sleep(1.0)    # let the clocks recover
         burst_ms = kernel_region(BURST_STEPS)
         fence()
-        if cpl[0] == 1 and info["filters_per_workgroup"] == 4:
+        if cpl[0] == 1 and info["filters_per_workgroup"] == 4 and not tracking:
             # the same cycles once more as launches of MULTI_CYCLES cycles (ukfb_cycle_multi_dev): the filters stay in LDS
             # between the cycles of a launch.  Reported beside the headline, never as `value`.
             restore()
@@ -700,7 +719,8 @@ def run_rank(args):
                                     f"{total} PoseWithVelocity UKF filters, fused predict("
                                     + ("constant-velocity branch" if args.workload == "pose-cv" else "acc branch") + ", dt=0.01)+"
                                     + ("per-filter measurement model (9 models, 25 % inactive)" if args.workload == "pose-mixed"
-                                       else "PositionMeasurement") + f" update per step, {args.precision}, {per} filters per GPU"),
+                                       else "PositionMeasurement") + f" update per step, {args.precision}, {per} filters per GPU"
+                                    + (", position fixes regenerated per step around the filter's own mean (--inputs tracking)" if tracking else "")),
                        "filters": total, "filters_per_gpu": per,
                        "lanes_per_filter": 64 // max(1, info["filters_per_workgroup"]),
                        "parallelism": f"filter-sharded x{world}"},

@@ -72,6 +72,12 @@ def test_bench_other_workloads_run():
     # SURVEY 8(d)'s secondary run: the constant-velocity branch (no acceleration latched)
     d = run_bench("--workload", "pose-cv", "--filters", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert "constant-velocity" in d["config"]["workload"] and d["status_or"] == 0 and d["parity"]["ok"] is True
+    # position fixes regenerated on the device, step by step, around the filter's own mean (inputs regenerated
+    # per cycle, nothing crosses PCIe inside the timed region); the oracle replay regenerates them the same way
+    for prec, tol in (("f64", 1e-9), ("f32", 1e-4)):
+        d = run_bench("--inputs", "tracking", "--precision", prec, "--filters", "8192", "--steps", "12", "--warmup", "3", "--no-cpu-baseline")
+        assert "tracking" in d["config"]["workload"] and d["status_or"] == 0 and d["multi_cycle"] is None
+        assert d["parity"]["ok"] is True and d["parity"]["tol"] == tol and d["parity_recent"]["ok"] is True
 
 
 def test_bench_cycles_per_launch():

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Builds an experimental engine variant next to the product library (never committed, not gated):
 #   tools/build_variant.sh <name> [extra hipcc flags...]  ->  slam-pose_estimation_amd/lib/ab/<name>.so
-# Used with tools/ab.sh for same-box A/B timing.
+# Used with tools/ab.sh for same-box A/B timing.  Same flags as csrc/Makefile (MachineLICM off for the kernel TUs only).
+# e.g. the rejected four-wavefront variant of round 3:  tools/build_variant.sh compact64 -DUKFB_COMPACT64=1 -DUKFB_LATE_XM=1
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -10,13 +11,18 @@ out=$root/slam-pose_estimation_amd/lib/ab
 obj=$out/obj_$name
 mkdir -p $obj
 pids=""
-for tu in ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -disable-machine-licm "$@" \
+common="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -DUKFB_GENERIC_F64=0"
+for tu in ukf_batch ukf_group; do
+  /opt/rocm/bin/hipcc $common "$@" -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.remarks &
+  pids="$pids $!"
+done
+for tu in ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
+  /opt/rocm/bin/hipcc $common -mllvm -disable-machine-licm "$@" \
       -Rpass-analysis=kernel-resource-usage -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.remarks &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
 python3 $root/tools/check_resources.py $obj/ukf_launch_*.remarks | grep kernel16 || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o -ldl
 rm -rf $obj
 echo "built $out/$name.so"

@@ -161,7 +161,17 @@ int ukfb_get_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count,
 int ukfb_device_views(ukfb_engine* e, void** mu_dev, void** cov_packed_dev, uint32_t** status_dev);
 
 /* ---- process noise / latched inputs ------------------------------------------------------ */
-/* setProcessNoiseCovariance (:130): one D x D matrix for the whole batch ... */
+/* setProcessNoiseCovariance (:130): one D x D matrix for the whole batch ...
+ * OrientationState engines: predictionStepImpl replaces the two leading 3x3 blocks N of the noise by R N R^T with the
+ * rotation matrix R of the current orientation (OrientationUKF.cpp:81-86).  For a batch-uniform noise whose two blocks are
+ * exact multiples of the identity, N = s I (the reference's zero default and every BASELINE configuration), the kernels
+ * skip the rotation while every orientation quaternion of the wavefront has | |q|^2 - 1 | <= 1e-9 (fp64 engines) / 1e-4
+ * (fp32 engines, where the stored norm drifts by ~1e-6 per hundred cycles): R s I R^T = s R R^T, and for Eigen's
+ * un-normalised toRotationMatrix R R^T = I + O(|q|^2 - 1).  Deviation from the always-rotating reference: at most
+ * 2 | |q|^2 - 1 | s dt^2 per entry and prediction -- 2e-4 relative to a noise entry that is itself ~1e-8 (config 4), i.e.
+ * ~1e-12 absolute against covariance entries of 1e-4 ... 1e-2 whose fp32 rounding is 1e-11 ... 1e-9: below the
+ * arithmetic's own rounding (profiles/r03_f32_drift_attribution.txt: the always-rotating build `d_iso` gives the same
+ * distances to the oracle).  Anisotropic blocks, per-filter noise and non-unit quaternions take the rotated path. */
 int ukfb_set_process_noise(ukfb_engine* e, const double* R);
 /* ... or one per filter ([count][D][D]); the first per-filter call switches the engine to
  * per-filter storage (initialised from the batch-uniform matrix). */

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the reference bench lines of a build (short, default and fp32), compact summary on stdout.
-out=gpurun_out/r02_$1; mkdir -p $out; shift
+out=gpurun_out/r03_$1; mkdir -p $out; shift
 export TMPDIR=/tmp
 run() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > $out/$name.json 2> $out/$name.err || tail -3 $out/$name.err;
   python3 - $out/$name.json $name <<'PY'
@@ -23,6 +23,13 @@ for what in "$@"; do
     cfg4) run cfg4 --no-cpu-baseline --workload orient --precision f32 --filters 4194304 ;;
     cfg4_64) run cfg4_64 --no-cpu-baseline --workload orient --filters 1048576 ;;
     cfg5) run cfg5 --no-cpu-baseline --workload pose-mixed --filters 262144 ;;
+    cfg5_order) run cfg5_order --no-cpu-baseline --workload pose-mixed --filters 262144 --bucket-models 0 ;;
+    cfg2_single) run cfg2_single --no-cpu-baseline --filters 65536 --split-streams 0 ;;
+    shard8) run shard8 --no-cpu-baseline --filters 131072 ;;
+    shard8_single) run shard8_single --no-cpu-baseline --filters 131072 --split-streams 0 ;;
+    f64_1000) run f64_1000 --no-cpu-baseline --steps 1000 --no-extra-regions ;;
+    track_1000) run track_1000 --no-cpu-baseline --steps 1000 --no-extra-regions --inputs tracking ;;
+    group2) run group2 --no-cpu-baseline --launcher group --gpus 2 --group-devices 0,0 ;;
     full) run full ;;
   esac
 done

@@ -10,7 +10,7 @@
 #        about 25 -- run parts 1 and 2 in two calls (their outputs merge in gpurun_out/pmc_configs) and then
 #        `python3 tools/pmc_report.py gpurun_out/pmc_configs <tag>` in the container; copy the json / csv files into profiles/
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 part=${2:-all}
 out=$PWD/gpurun_out/pmc_configs; mkdir -p $out
 export TMPDIR=/tmp
@@ -37,15 +37,17 @@ cfg() {  # name, bench args
 if [ $part != 2 ]; then
 cfg headline_f64
 cfg headline_f32 --precision f32
-cfg cfg2 --filters 65536
-cfg cfg3 --filters 131072 --precision f32
+# (small launches: one launch per cycle for the counters -- the default runs them as two half launches on two streams,
+#  whose per-dispatch counters would describe half a batch)
+cfg cfg2 --filters 65536 --split-streams 0
+cfg cfg3 --filters 131072 --precision f32 --split-streams 0
 cfg multi8_f64 --cycles-per-launch 8 --warmup 16
 fi
 if [ $part = 1 ]; then exit 0; fi
 cfg cfg4 --workload orient --precision f32 --filters 4194304
 cfg cfg5 --workload pose-mixed --filters 262144
 cfg multi8_f32 --cycles-per-launch 8 --warmup 16 --precision f32
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --filters 65536 > $out/trace_cfg2.json 2> $out/trace_cfg2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --filters 65536 --split-streams 0 > $out/trace_cfg2.json 2> $out/trace_cfg2.err
 # kernel stats of the default command (the driver's own invocation and the 500-step default)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions > $out/trace_default.json 2> $out/trace_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --precision f32 > $out/trace_f32.json 2> $out/trace_f32.err

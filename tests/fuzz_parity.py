@@ -8,7 +8,7 @@ the fused cycle) and compares state, covariance and status word after every laun
 Tolerances: north_star's 1e-9 (fp64) / 1e-4 (fp32), relative to the size of the covariance where a scenario makes the
 UKF ill-conditioned (entries above 1).  Prints one line per failing scenario and a summary; exit code 1 on any failure.
 
-usage: python3 tools/fuzz_parity.py [scenarios=200] [seed=1]"""
+usage: python3 tests/fuzz_parity.py [scenarios=200] [seed=1]"""
 import os
 import sys
 

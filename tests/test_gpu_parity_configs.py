@@ -294,13 +294,12 @@ def test_full_size_config5_mixed_fp64(spe, oracle):
 
 
 def test_randomised_scenarios_against_the_oracle():
-    """tools/fuzz_parity.py: batch sizes 1..256 (ragged wavefronts), both precisions, covariance scales over six decades, spins,
+    """tests/fuzz_parity.py: batch sizes 1..256 (ragged wavefronts), both precisions, covariance scales over six decades, spins,
     time steps, missing accelerations, per-filter models with inactive filters, random SPD measurement covariances, optional
     Mahalanobis gate; separate launches and the fused cycle, Pose and Orient; state, covariance and status after every launch."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                              "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     fails = fz.run(120, 7)

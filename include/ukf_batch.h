@@ -233,6 +233,9 @@ int ukfb_update_dev(ukfb_engine* e, int meas_model_uniform, const int32_t* meas_
                     const void* Q_dev);
 
 /* ---- fused cycle: predictionStep(dt) followed by integrateMeasurement, one launch -------- */
+/* The host-array forms (ukfb_cycle, ukfb_cycle_uniform_q) upload their samples on a separate copy stream into one of two
+ * staging sets, so that the upload of call k + 1 overlaps the kernel of call k; they return when the caller's arrays have been
+ * consumed (the arrays may be rewritten at once), not when the kernel is done. */
 int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q);
 int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int32_t* meas_model_dev, const void* z_dev,
                    const void* Q_dev);

@@ -177,9 +177,100 @@ int fill_scalar(ukfb_engine* e, void* dst_dev, size_t n, double value) {
 int launch(ukfb_engine* e, const ukfb::LaunchReq& r) {
     if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
     HIP_TRY(hipSetDevice(e->device));
+    if (r.wait_event) HIP_TRY(hipStreamWaitEvent(ukfb::main_stream(e), r.wait_event, 0));
+    int rc;
     if (e->model == UKFB_MODEL_POSE)
-        return e->prec == UKFB_F64 ? ukfb::launch_pose_f64(e, r) : ukfb::launch_pose_f32(e, r);
-    return e->prec == UKFB_F64 ? ukfb::launch_orient_f64(e, r) : ukfb::launch_orient_f32(e, r);
+        rc = e->prec == UKFB_F64 ? ukfb::launch_pose_f64(e, r) : ukfb::launch_pose_f32(e, r);
+    else
+        rc = e->prec == UKFB_F64 ? ukfb::launch_orient_f64(e, r) : ukfb::launch_orient_f32(e, r);
+    if (!rc && r.done_event) HIP_TRY(hipEventRecord(r.done_event, ukfb::main_stream(e)));
+    return rc;
+}
+
+// ---- host-fed fused cycles: double-buffered staging on a copy stream ----------------------------------------------------
+// ukfb_cycle / ukfb_cycle_uniform_q upload z and Q before they launch.  On the engine's own stream that upload queues
+// behind the kernel of the previous call: copy and kernel alternate (1 M Pose filters fp64: 2.0 ms of PCIe + 1.1 ms of
+// kernel per cycle).  Here the upload of call k + 1 runs on a separate stream into the staging set call k is not reading;
+// the call returns when ITS copies have been consumed (the caller's buffers are free), not when the kernel is done.
+struct Staged {
+    void* z = nullptr;
+    void* Q = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    int slot = 0;
+};
+
+int ensure_copy_path(ukfb_engine* e) {
+    if (e->copy_stream) return UKFB_OK;
+    const size_t n = size_t(e->cap), ts = e->tsize;
+    hipStream_t cs = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (int s = 0; s < 2; ++s) {
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_copy[s], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_used[s], hipEventDisableTiming));
+        HIP_TRY(hipMalloc(&e->zc_stage[s], n * 3 * ts));
+        HIP_TRY(hipMalloc(&e->Qc_stage[s], n * 9 * ts));
+    }
+    e->copy_stream = cs;
+    return UKFB_OK;
+}
+
+// host doubles -> device array in engine precision, enqueued on the copy stream (no wait)
+int upload_on_copy_stream(ukfb_engine* e, void* dst_dev, const double* src, size_t n) {
+    if (n == 0) return UKFB_OK;
+    if (e->prec == UKFB_F64) {
+        HIP_TRY(hipMemcpyAsync(dst_dev, src, n * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+        return UKFB_OK;
+    }
+    // fp32: the doubles cross PCIe as they are and are narrowed on the device (cf. upload)
+    HIP_TRY(hipMemcpyAsync(e->cvt_copy, src, n * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+    hipLaunchKernelGGL(narrow_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, e->copy_stream,
+                       static_cast<const double*>(e->cvt_copy), static_cast<float*>(dst_dev), n);
+    HIP_TRY(hipGetLastError());
+    return UKFB_OK;
+}
+
+hipError_t wait_stream_polling(hipStream_t s);
+
+int stage_cycle_inputs(ukfb_engine* e, const double* z, const double* Q, size_t nq, Staged* out) {
+    if (!z || !Q) return fail(UKFB_ERR_INVALID_ARG, "z and Q must not be NULL");
+    if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
+    int rc = ensure_copy_path(e);
+    if (rc) return rc;
+    const size_t nz = size_t(e->cap) * 3;
+    if (e->prec == UKFB_F32) {   // scratch for the widest array of the call; z and Q pass through it one after the other
+        const size_t need = std::max(nz, nq) * sizeof(double);
+        if (e->cvt_copy_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(e->copy_stream));
+            if (e->cvt_copy) HIP_TRY(hipFree(e->cvt_copy));
+            e->cvt_copy = nullptr;
+            e->cvt_copy_bytes = 0;
+            HIP_TRY(hipMalloc(&e->cvt_copy, need));
+            e->cvt_copy_bytes = need;
+        }
+    }
+    const int s = e->stage_slot;
+    e->stage_slot ^= 1;
+    if (e->stage_busy[s]) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_used[s], 0));   // the kernel that read this set is done
+    rc = upload_on_copy_stream(e, e->zc_stage[s], z, nz);
+    if (!rc) rc = upload_on_copy_stream(e, e->Qc_stage[s], Q, nq);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev_copy[s], e->copy_stream));
+    // the caller's buffers are free again once the copies have been consumed: wait for the COPY stream only (bounded)
+    {
+        const hipError_t w = wait_stream_polling(e->copy_stream);
+        if (w == hipErrorNotReady && g_wait_timed_out) {
+            e->poisoned = true;
+            g_wait_timed_out = false;
+            return UKFB_ERR_HIP;
+        }
+        HIP_TRY(w);
+    }
+    out->z = e->zc_stage[s];
+    out->Q = e->Qc_stage[s];
+    out->ready = e->ev_copy[s];
+    out->done = e->ev_used[s];
+    out->slot = s;
+    return UKFB_OK;
 }
 
 bool meas_model_ok(const ukfb_engine* e, int m) {
@@ -530,7 +621,7 @@ template <class Query> static hipError_t wait_polling(Query&& query) {
     }
     return r;
 }
-static hipError_t wait_stream_polling(hipStream_t s) { return wait_polling([s] { return hipStreamQuery(s); }); }
+namespace { hipError_t wait_stream_polling(hipStream_t s) { return wait_polling([s] { return hipStreamQuery(s); }); } }
 static hipError_t wait_event_polling(hipEvent_t ev) { return wait_polling([ev] { return hipEventQuery(ev); }); }
 
 namespace {
@@ -682,6 +773,14 @@ int ukfb_destroy(ukfb_engine* e) {
         if (b) (void)hipFree(b);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (e->zc_stage[s2]) (void)hipFree(e->zc_stage[s2]);
+        if (e->Qc_stage[s2]) (void)hipFree(e->Qc_stage[s2]);
+        if (e->ev_copy[s2]) (void)hipEventDestroy(e->ev_copy[s2]);
+        if (e->ev_used[s2]) (void)hipEventDestroy(e->ev_used[s2]);
+    }
+    if (e->cvt_copy) (void)hipFree(e->cvt_copy);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->ev_a) (void)hipEventDestroy(e->ev_a);
     if (e->ev_b) (void)hipEventDestroy(e->ev_b);
     if (e->stream_b) (void)hipStreamDestroy(e->stream_b);
@@ -1277,10 +1376,23 @@ int ukfb_cycle_uniform_q(ukfb_engine* e, double dt, int meas_model, const double
     if (!e || !z || !Q9) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
     HIP_TRY(hipSetDevice(e->device));
-    int rc = upload(e, e->z_stage, 0, z, size_t(e->cap) * 3);
-    if (!rc) rc = upload(e, e->Q_stage, 0, Q9, 9);
+    Staged sg;
+    const int rc = stage_cycle_inputs(e, z, Q9, 9, &sg);
     if (rc) return rc;
-    return ukfb_cycle_uniform_q_dev(e, dt, meas_model, e->z_stage, e->Q_stage);
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.do_update = true;
+    r.dt_uniform = dt;
+    r.meas_uniform = meas_model;
+    r.z_dev = sg.z;
+    r.Q_dev = sg.Q;
+    r.q_uniform = true;
+    r.wait_event = sg.ready;
+    r.done_event = sg.done;
+    r.no_split = true;
+    const int lrc = launch(e, r);
+    if (!lrc) e->stage_busy[sg.slot] = true;
+    return lrc;
 }
 
 int ukfb_update_uniform_q(ukfb_engine* e, int meas_model, const double* z, const double* Q9, const uint8_t* active) {
@@ -1305,9 +1417,22 @@ int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
     HIP_TRY(hipSetDevice(e->device));
-    int rc = stage_measurements(e, z, Q, nullptr, nullptr);
+    Staged sg;
+    const int rc = stage_cycle_inputs(e, z, Q, size_t(e->cap) * 9, &sg);
     if (rc) return rc;
-    return ukfb_cycle_dev(e, dt, meas_model, nullptr, e->z_stage, e->Q_stage);
+    ukfb::LaunchReq r;
+    r.do_predict = true;
+    r.do_update = true;
+    r.dt_uniform = dt;
+    r.meas_uniform = meas_model;
+    r.z_dev = sg.z;
+    r.Q_dev = sg.Q;
+    r.wait_event = sg.ready;
+    r.done_event = sg.done;
+    r.no_split = true;
+    const int lrc = launch(e, r);
+    if (!lrc) e->stage_busy[sg.slot] = true;
+    return lrc;
 }
 
 int ukfb_cycle_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev, const int32_t* meas_model_dev, const void* z_dev,

@@ -66,6 +66,17 @@ struct ukfb_engine {
     double* dt_stage = nullptr;
     int64_t* ts_stage = nullptr;
     uint32_t* reduce_word = nullptr;  // status OR-reduction target
+    // Host-fed fused cycles (ukfb_cycle, ukfb_cycle_uniform_q): the samples of call k + 1 are uploaded on a COPY stream into
+    // the other of two staging sets while the kernel of call k still runs on the engine's stream (created at the first such
+    // call).  ev_copy[s]: set s is uploaded; ev_used[s]: the kernel that read set s has finished.
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    void* zc_stage[2] = {nullptr, nullptr};   // [cap][3]
+    void* Qc_stage[2] = {nullptr, nullptr};   // [cap][9]
+    bool stage_busy[2] = {false, false};
+    int stage_slot = 0;
+    void* cvt_copy = nullptr;                 // fp32 engines: scratch of the copy stream (host doubles narrowed on the device)
+    size_t cvt_copy_bytes = 0;
     // fp32 engines: device scratch for host doubles that are narrowed on the device (grow-only)
     void* cvt_dev = nullptr;
     size_t cvt_bytes = 0;
@@ -112,6 +123,10 @@ struct LaunchReq {
     const void* in_b_slots = nullptr;
     const double* sched_dt = nullptr;        // host, [cycles]: per-cycle time steps and models (both or neither)
     const int32_t* sched_model = nullptr;
+    // host-fed cycles: the launch waits for `wait_event` (inputs uploaded on the copy stream) and records `done_event`
+    // behind the kernel; no_split keeps it one kernel on the engine's stream (the event then covers all of it)
+    hipEvent_t wait_event = nullptr, done_event = nullptr;
+    bool no_split = false;
 };
 
 int launch_pose_f64(ukfb_engine* e, const LaunchReq& r);

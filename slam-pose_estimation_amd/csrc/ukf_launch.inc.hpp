@@ -128,7 +128,7 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     // launch k + 1's first half follows launch k's first half on `stream`, its second half follows launch k's second half on
     // stream_b -- the tail of one half (a partly empty last round of workgroups) overlaps the head of the other stream's next
     // kernel.  Filters are independent, the halves touch disjoint filters: results are bit-identical.
-    if (!args.fidx && e->stream_b && e->cfg.split_streams && args.n >= SPLIT_MIN_FILTERS && args.n < split_max_filters()) {
+    if (!args.fidx && !r.no_split && e->stream_b && e->cfg.split_streams && args.n >= SPLIT_MIN_FILTERS && args.n < split_max_filters()) {
         KArgs<T> h1 = args, h2 = args;
         h1.n = (args.n / 2 + FPW - 1) / FPW * FPW;
         h2.item0 = h1.n;

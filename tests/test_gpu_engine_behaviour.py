@@ -599,3 +599,52 @@ def test_split_launches_are_bit_identical(spe, prec):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert (out[0][2] == out[1][2]).all() and out[0][3] == out[1][3] == 0
     assert np.isfinite(out[0][0]).all() and max_abs(out[0][0], mu) > 1e-3
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_host_fed_cycles_overlap_their_uploads(spe, oracle, prec):
+    """ukfb_cycle / ukfb_cycle_uniform_q upload the samples of call k + 1 on a copy stream, into the staging set call k is
+    not reading, while the kernel of call k still runs; the call returns when its copies have been consumed.  The CALLER'S
+    arrays are therefore free at return: this test overwrites them in place right after every call (no synchronise), mixes the
+    two host entry points with a device-pointer cycle and a state download, and must still equal the same cycles fed through
+    the device-pointer entry point (bit for bit) and the oracle."""
+    import torch
+    n = 40_001
+    s = spe.synth
+    tdt = torch.float64 if prec == 0 else torch.float32
+    mu, cov = s.pose_initial(n)
+    ring = [s.pose_cycle_inputs(n, k, mu[:, :3]) for k in range(5)]
+    acc_cov = 0.01 * np.eye(3)
+    Q1 = ring[0][2][0].copy()                 # the synthetic Q is one 3x3 for every filter
+    host = spe.BatchPoseUKF(n, precision=prec, stream="private")
+    devp = spe.BatchPoseUKF(n, precision=prec, stream="private")
+    for e in (host, devp):
+        e.initialize(mu, cov)
+        e.set_acceleration(ring[0][0], acc_cov)
+    zbuf, Qbuf = np.empty((n, 3)), np.empty((n, 3, 3))
+    for k in range(5):
+        zbuf[...] = ring[k][1]; Qbuf[...] = ring[k][2]
+        if k % 2 == 0:
+            host.cycle(0.01, spe.MEAS_POS3, zbuf, Qbuf)
+        else:
+            host.cycle_uniform_q(0.01, spe.MEAS_POS3, zbuf, Q1)
+        zbuf[...] = np.nan; Qbuf[...] = np.nan          # the caller reuses its arrays at once
+        if k == 2:
+            m_mid, _, _ = host.state(0, 16)               # a download in between joins the streams
+            assert np.isfinite(m_mid).all()
+        z_t = torch.from_numpy(ring[k][1]).to("cuda", tdt)
+        Q_t = torch.from_numpy(ring[k][2].reshape(n, 9)).to("cuda", tdt)
+        torch.cuda.synchronize()
+        devp.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t)
+        devp.sync()
+    mh, ch, _ = host.state(); md, cd, _ = devp.state()
+    assert np.array_equal(mh, md) and np.array_equal(ch, cd) and host.status_summary() == 0
+    k4 = 2048
+    cast = (lambda x: x) if prec == 0 else (lambda x: x.astype(np.float32).astype(np.float64))
+    m_o, c_o = mu[:k4].copy(), cov[:k4].copy()
+    for k in range(5):
+        m_o, c_o, _ = oracle.pose_predict(m_o, c_o, s.pose_default_process_noise(), cast(ring[0][0][:k4]), acc_cov, 0.01, threads=8)
+        m_o, c_o, _ = oracle.pose_update(m_o, c_o, 0, cast(ring[k][1][:k4]), cast(ring[k][2][:k4]), threads=8)
+    tol = 1e-9 if prec == 0 else 1e-4
+    assert max_abs(mh[:k4], m_o) <= tol and max_abs(ch[:k4], c_o) <= tol
+    host.close(); devp.close()

@@ -225,6 +225,9 @@ template <class T> struct MT<OrientM<T>> {
 #ifndef UKFB_COMPACT64
 #define UKFB_COMPACT64 0  // 1 (with UKFB_LATE_XM=1): fp64 Pose on the compact 316-scalar LDS slice (Layout16::COMPACT), 4 wavefronts per SIMD -- measured and rejected; 0: the plain 396-scalar slice
 #endif
+#ifndef UKFB_ORIENT64_TRIM
+#define UKFB_ORIENT64_TRIM 1   // 0: the OrientationState fp64 slice of round 2 (14 656 B, 10 workgroups per CU)
+#endif
 #ifndef UKFB_F32_TRIM
 #define UKFB_F32_TRIM 1   // 0: the fp32 Pose slice as before round 2's last trim (424 floats, 21 workgroups per CU): -2.7 %
 #endif
@@ -250,7 +253,10 @@ template <class T, class M> struct Layout16 {
     static constexpr int LC = 0;                            // D*LS : unscaled factor columns
     // delta table rows 0..N-1 alias the factor (dead once every lane holds its column); its zero row lies behind it
     static constexpr int TNL = (D * LS > N * ST) ? (D * LS - N * ST) : 0;
-    static constexpr bool LAF_ROW_D = !(M::MODEL == 0 && (sizeof(T) == 8 || UKFB_F32_TRIM));   // only the Pose slices need the trim
+    // OrientationState fp64 (round 3): the same two trims bring its slice from 14 656 B to 14 016 B = 11 instead of 10
+    // one-wave workgroups per CU (11 LDS allocation granules of 1 280 B; its 146 VGPRs allow 12)
+    static constexpr bool ORIENT64_TRIM = (M::MODEL == 1 && sizeof(T) == 8 && UKFB_ORIENT64_TRIM != 0);
+    static constexpr bool LAF_ROW_D = !((M::MODEL == 0 && (sizeof(T) == 8 || UKFB_F32_TRIM)) || ORIENT64_TRIM);
     // fp32 Pose: the small regions packed to 8-byte instead of 16-byte boundaries bring the slice to 400 floats = 6400 B =
     // 5 allocation granules: 24 workgroups per CU = 6 wavefronts per SIMD (77 VGPRs allow it)
     static constexpr int alm(int x) { return (M::MODEL == 0 && sizeof(T) == 4 && UKFB_F32_TRIM) ? (x + 1) / 2 * 2 : al(x); }
@@ -280,10 +286,15 @@ template <class T, class M> struct Layout16 {
     static constexpr int ROT = COMPACT ? LC : (MUS + alm(S));   // 9  : rotation matrix of the mean
     static constexpr int ZQ = COMPACT ? (MUS + alm(S)) : (ROT + alm(9));   // 12 : z (3) + Q (9)
     static constexpr int NSH = ZQ + 12;                     // 21 : shaped process noise of the nonlinear block
-    static constexpr int NSH_SINK = COMPACT ? (NSH + 21) : (NSH + alm(21));   // where the fill of NSH sends its idle lanes
-    static constexpr int DUM = COMPACT ? NSH : (NSH + alm(21));   // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
-    static constexpr int PF_RAW = COMPACT ? (NSH + alm(21)) : (DUM + alm(S));
-    static_assert(!COMPACT || (alm(21) > 21 && alm(21) >= S && 10 <= TNL), "compact layout: sink and rotation matrix fit their hosts");
+    // SINK_IN_NSH: the store sink IS the shaped-noise table.  Safe because while that table is live (from its fill to the last
+    // fetch of one of its entries) every sink store is a single scalar and goes to the table's spare slot NSH_SINK; all other
+    // sink stores (up to S scalars from the sink's base) happen while the table is dead.
+    static constexpr bool SINK_IN_NSH = COMPACT || ORIENT64_TRIM;
+    static constexpr int NSH_SINK = SINK_IN_NSH ? (NSH + 21) : (NSH + alm(21));   // where stores inside the table's live window send their idle lanes
+    static constexpr int DUM = SINK_IN_NSH ? NSH : (NSH + alm(21));   // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
+    static constexpr int PF_RAW = SINK_IN_NSH ? (NSH + alm(21)) : (DUM + alm(S));
+    static_assert(!SINK_IN_NSH || (alm(21) > 21 && alm(21) >= S), "the sink fits the noise table, which has a spare slot");
+    static_assert(!COMPACT || 10 <= TNL, "compact layout: the rotation matrix fits the head of the factor region");
     // LDS index (from the slice base) of covariance entry (r, c), c <= r
     __host__ __device__ static constexpr int cv(int r, int c) {
         if (!COMPACT) return PKS + r * (r + 1) / 2 + c;
@@ -1476,7 +1487,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                             // (isotropic blocks, noise_plain: the table entry itself, no rotation and no rotation matrix)
                             const T ne = (M::MODEL != 0 && noise_plain) ? plain_noise_entry16<T, M>(Rn, Ra, pin, r, c)
                                                                         : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
-                            NSH[v ? (l + G * t) : (LY::DUM - LY::NSH)] = ne;
+                            NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = ne;
                         }
                         if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
 #pragma unroll
@@ -1556,7 +1567,8 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                                     }
                                 }
                                 const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
-                                PKS[w ? (r * (r + 1) / 2 + c) : (LY::DUM - LY::PKS)] = tot + nv;
+                                // (idle lanes: the noise table's spare slot -- the table may still be read by the next entries)
+                                PKS[w ? (r * (r + 1) / 2 + c) : (LY::NSH_SINK - LY::PKS)] = tot + nv;
                             }
                     };
                     if (!NZ_EARLY && noise_plain) store_tiles(std::true_type{});

@@ -536,6 +536,10 @@ class UKFGroup:
         mu = _f64(mu, (-1, self.S)); cov = _f64(cov, (-1, self.D, self.D))
         _chk(self._lib.ukfb_group_initialize(self._g, C.c_int64(first), C.c_int64(mu.shape[0]), _pd(mu), _pd(cov)),
              "ukfb_group_initialize")
+        if self.model == MODEL_ORIENT:   # the reference constructor's input latches (OrientationUKF.cpp:49-50), as BatchOrientationUKF
+            n = mu.shape[0]
+            acc = np.zeros((n, 3)); acc[:, 2] = mu[:, 13]
+            self.set_orient_inputs(gyro=np.zeros((n, 3)), acc=acc, first=first)
 
     def state(self, first: int = 0, count: Optional[int] = None):
         count = self.total - first if count is None else count

@@ -91,3 +91,32 @@ def test_one_device_group_gathers_over_rccl(spe, prec):
     grp.sync()
     assert np.array_equal(out[0].double().cpu().numpy(), mg)
     grp.close(); one.close()
+
+
+def test_orientation_group_equals_the_unsharded_batch(spe):
+    """OrientationState filters through the group entry points (parameters, latched IMU inputs, prediction, body-velocity
+    update, fused cycle from host arrays) against one BatchOrientationUKF: bit for bit, three ragged shards on one device."""
+    n = 1031
+    s = spe.synth
+    mu, cov = s.orient_initial(n)
+    one = spe.BatchOrientationUKF(n, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE)
+    grp = spe.UKFGroup(spe.MODEL_ORIENT, spe.F64, n, [0, 0, 0])
+    grp.set_orient_params(s.ORIENT_TAU, s.ORIENT_TAU, one.earth_rotation)
+    for e in (one, grp):
+        e.set_process_noise(s.orient_process_noise())
+        e.initialize(mu, cov)
+        e.predict(0.02)                                   # before any IMU sample: the constructor's latches
+    for k in range(2):
+        gyro, acc, z, Q = s.orient_cycle_inputs(n, k, mu[:, :4])
+        for e in (one, grp):
+            e.set_orient_inputs(gyro, acc)
+            if k == 0:
+                e.cycle(0.01, spe.MEAS_ORIENT_BODYVEL3, z, Q)
+            else:
+                e.predict(0.01)
+                e.update(spe.MEAS_ORIENT_BODYVEL3, z, Q)
+    grp.sync()
+    m1, c1, _ = one.state(); mg, cg, _ = grp.state()
+    assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and grp.status_summary() == one.status_summary() == 0
+    assert max_abs(m1, mu) > 1e-4 and [sh["count"] for sh in grp.shards] == [344, 344, 343]
+    grp.close(); one.close()

@@ -229,3 +229,36 @@ def test_time_gate_matches_reference_semantics(oracle, onp):
 
 def test_earth_rate_constant(oracle):
     assert oracle.earthw() == (2.0 * np.pi) / 86164.0   # GravitationalModel.hpp:16
+
+
+def test_so3_conventions_against_scipy_rotation(oracle, onp):
+    """An implementation nobody here wrote: scipy.spatial.transform.Rotation (Hamilton quaternions, scalar LAST = Eigen's
+    coefficient order x, y, z, w that the reference's BodyStateMeasurement.hpp:17 and the C-ABI use).  Pins the conventions the
+    recalled MTK semantics stand on -- exp = rotation vector -> quaternion, log its inverse on the principal branch, q * v the
+    active rotation of a vector (Eigen's operator*), matrix(), and boxplus as RIGHT multiplication q <- q * exp(delta)
+     -- in both restatements of the oracle."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        v = rng.uniform(-1.0, 1.0, 3) * rng.choice([1e-9, 1e-3, 0.3, 1.5, 3.0])
+        q_ref = R.from_rotvec(v).as_quat()                       # x, y, z, w
+        q = oracle.so3_exp(v)
+        assert max_abs(q, q_ref) <= 1e-14 and max_abs(onp.so3_exp(v[None])[0], q_ref) <= 1e-14
+        if np.linalg.norm(v) < np.pi - 1e-3:                      # principal branch: log(exp(v)) = v
+            assert max_abs(oracle.so3_log(q_ref), R.from_quat(q_ref).as_rotvec()) <= 1e-12
+        qa = rand_quat(rng)
+        x = rng.uniform(-2, 2, 3)
+        assert max_abs(oracle.quat_rotate(qa, x), R.from_quat(qa).apply(x)) <= 1e-13
+        assert max_abs(oracle.quat_to_matrix(qa), R.from_quat(qa).as_matrix()) <= 1e-13
+        # boxplus on the Pose manifold: position / velocity / angular velocity add, orientation right-multiplies
+        state = np.concatenate([rng.uniform(-1, 1, 3), qa, rng.uniform(-1, 1, 6)])
+        d = rng.uniform(-0.5, 0.5, 12)
+        out = oracle.pose_boxplus(state, d)
+        q_expect = (R.from_quat(qa) * R.from_rotvec(d[3:6])).as_quat()
+        q_expect = q_expect if np.dot(q_expect, out[3:7]) > 0 else -q_expect   # q and -q are the same rotation
+        assert max_abs(out[3:7], q_expect) <= 1e-13
+        assert max_abs(out[:3], state[:3] + d[:3]) <= 1e-15 and max_abs(out[7:], state[7:] + d[6:]) <= 1e-15
+        # ... and boxminus undoes it: (x [+] d) [-] x = d, the tangent of the relative rotation x^-1 (x [+] d)
+        back = oracle.pose_boxminus(out, state)
+        rel = (R.from_quat(qa).inv() * R.from_quat(out[3:7])).as_rotvec()
+        assert max_abs(back[3:6], rel) <= 1e-12 and max_abs(back, d) <= 1e-12

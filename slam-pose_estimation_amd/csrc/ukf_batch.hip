@@ -415,6 +415,13 @@ template <class T> int import_body_states(ukfb_engine* e, int64_t first, int64_t
     return UKFB_OK;
 }
 
+// Class of a filter's update in a call: 0 = none (negative / invalid model id: prediction only), 1 = closed form (the eight
+// linear sub-state selections of PoseUKF), 2 = sigma-point path (PoseUKF OrientationMeasurement, OrientationUKF body velocity)
+__device__ __forceinline__ int update_class(int engine_model, int mid) {
+    if (engine_model == UKFB_MODEL_POSE) return (mid < 0 || mid > 8) ? 0 : ((mid == 3) ? 2 : 1);
+    return (mid == 9) ? 2 : 0;
+}
+
 // ---- device-side ordering of an event stream ------------------------------------------------------------
 __global__ void events_init_kernel(const int64_t* filt, const int64_t* ts, int64_t n, int64_t cap, uint32_t* idx,
                                    int64_t* key_t, uint32_t* flags) {
@@ -435,19 +442,24 @@ __global__ void events_heads_kernel(const uint32_t* key_f_sorted, int64_t n, uin
     if (k >= n) return;
     head[k] = (k == 0 || key_f_sorted[k] != key_f_sorted[k - 1]) ? uint32_t(k) : 0u;
 }
-__global__ void events_rank_kernel(const uint32_t* start, int64_t n, uint32_t* rank, uint32_t* flags) {
+// rank of a sample inside its filter's run = its round.  The sort key of the round-major order also carries the class of the
+// sample's update (2 bits, most expensive first): inside a round the indirect launch then runs class-uniform wavefronts
+// (all but the one or two that straddle a class boundary), as the model-class buckets of ukfb_cycle_dev do
+__global__ void events_rank_kernel(const uint32_t* start, const uint32_t* idx, const int32_t* meas, int engine_model, int64_t n,
+                                   uint32_t* key, uint32_t* flags) {
     const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
     if (k >= n) return;
     const uint32_t r = uint32_t(k) - start[k];
-    rank[k] = r;
+    if (r >= (1u << 30)) atomicOr(&flags[0], 2u);   // a billion samples of one filter in one call: not representable in the key
+    key[k] = (r << 2) | uint32_t(2 - update_class(engine_model, meas[idx[k]]));
     atomicMax(&flags[1], r);
 }
 // first position of every round in the (rank, filter)-ordered event list; off[rounds] = n
-__global__ void events_round_offsets_kernel(const uint32_t* rank_sorted, int64_t n, uint32_t* off) {
+__global__ void events_round_offsets_kernel(const uint32_t* key_sorted, int64_t n, uint32_t* off) {
     const int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
     if (p >= n) return;
-    const uint32_t r = rank_sorted[p];
-    if (p == 0 || rank_sorted[p - 1] != r) off[r] = uint32_t(p);
+    const uint32_t r = key_sorted[p] >> 2;
+    if (p == 0 || (key_sorted[p - 1] >> 2) != r) off[r] = uint32_t(p);
     if (p == n - 1) off[r + 1] = uint32_t(n);
 }
 // events in their final (round-major, filter-minor) order, compact and in the engine's precision: what the
@@ -468,17 +480,11 @@ __global__ void events_gather_kernel(const int64_t* filt, const int64_t* ts, con
 
 
 // ---- model-class buckets (ukfb_cycle_dev with per-filter model ids) ---------------------------------------
-// Class of a filter's update in this call: 0 = none (negative / invalid model id: prediction only), 1 = closed form (the eight
-// linear sub-state selections of PoseUKF), 2 = sigma-point path (PoseUKF OrientationMeasurement, OrientationUKF body velocity).
-// A stable three-way partition of the filter indices, two passes over the model ids: (1) per-block class counts, (2) every
+// A stable three-way partition (by update_class above) of the filter indices, two passes over the model ids: (1) per-block class counts, (2) every
 // block finds its offsets by summing the counts of the blocks before it (a few thousand values at most) and scatters.  The
 // classes follow each other from the most expensive to the cheapest, each
 // starts at a multiple of 4 (one wavefront = 4 filters); the list was pre-filled with -1, so the gaps read as padding.
 constexpr int BK_THREADS = 256, BK_PER_THREAD = 4, BK_BLOCK = BK_THREADS * BK_PER_THREAD;
-__device__ __forceinline__ int update_class(int engine_model, int mid) {
-    if (engine_model == UKFB_MODEL_POSE) return (mid < 0 || mid > 8) ? 0 : ((mid == 3) ? 2 : 1);
-    return (mid == 9) ? 2 : 0;
-}
 __global__ void __launch_bounds__(BK_THREADS) bucket_count_kernel(const int32_t* meas, int64_t n, int engine_model, uint32_t* counts,
                                                                   int nblocks) {
     using Reduce = hipcub::BlockReduce<uint32_t, BK_THREADS>;
@@ -1529,7 +1535,7 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     hipLaunchKernelGGL(events_heads_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), key_f_b, n, head);
     tb = tmp_bytes;
     HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, start, hipcub::Max(), int(n), ukfb::main_stream(e)));
-    hipLaunchKernelGGL(events_rank_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), start, n, rank, flags);
+    hipLaunchKernelGGL(events_rank_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), start, idx_c, d_m, e->model, n, rank, flags);
     tb = tmp_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, rank, rank_sorted, idx_c, idx_d, int(n), 0, 32, ukfb::main_stream(e)));
     hipLaunchKernelGGL(events_round_offsets_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), rank_sorted, n, off);
@@ -1545,7 +1551,8 @@ int process_events_device(ukfb_engine* e, int64_t n, const int64_t* d_f, const i
     uint32_t hflags[2] = {0, 0};
     int rc = download_raw(e, flags, hflags, 2);
     if (rc) return rc;
-    if (hflags[0]) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
+    if (hflags[0] & 1u) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: filter index or timestamp out of range");
+    if (hflags[0] & 2u) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_process_events: more than 2^30 samples of one filter in one call");
     const int64_t nrounds = int64_t(hflags[1]) + 1;
     std::vector<uint32_t> hoff(size_t(nrounds) + 1);
     rc = download_raw(e, off, hoff.data(), hoff.size());

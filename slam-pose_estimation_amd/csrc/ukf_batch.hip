@@ -1164,6 +1164,22 @@ int ukfb_update(ukfb_engine* e, int meas_model, const double* z, const double* Q
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
     HIP_TRY(hipSetDevice(e->device));
+    if (!active) {   // the common form: samples uploaded on the copy stream while the previous kernel runs (see stage_cycle_inputs)
+        Staged sg;
+        const int src = stage_cycle_inputs(e, z, Q, size_t(e->cap) * 9, &sg);
+        if (src) return src;
+        ukfb::LaunchReq r;
+        r.do_update = true;
+        r.meas_uniform = meas_model;
+        r.z_dev = sg.z;
+        r.Q_dev = sg.Q;
+        r.wait_event = sg.ready;
+        r.done_event = sg.done;
+        r.no_split = true;
+        const int lrc = launch(e, r);
+        if (!lrc) e->stage_busy[sg.slot] = true;
+        return lrc;
+    }
     int rc = stage_measurements(e, z, Q, nullptr, active);
     if (rc) return rc;
     ukfb::LaunchReq r;

@@ -280,6 +280,11 @@ template <class T, class M> struct Layout16 {
                                                             // (read by the cross lanes in their last trip) is not stored: it aliases the
                                                             // mean staging behind it - finite values that meet the table's exact-zero row
     static constexpr int LAF_SZ = al((D + (LAF_ROW_D ? 1 : 0)) * ST);
+    // Where the zero row D is not stored the cross lanes' last trip reads the ST scalars behind row D - 1: the mean staging
+    // (finite) -- and, if D * ST is not a multiple of the alignment, the PAD scalars in between, which nothing else ever writes.
+    // Uninitialised LDS times the table's exact zero is NaN if the leftover happens to be NaN or Inf: the pad is zeroed with
+    // the factor rows (found by tests/fuzz_parity.py as a box-dependent Cholesky failure of one OrientationState filter).
+    static constexpr int LAF_PAD = LAF_ROW_D ? 0 : (LAF_SZ - D * ST);
     static_assert(!COMPACT || (LAF_SZ >= NREST && !LAF_ROW_D), "compact layout: LAF covers REST and is followed by the mean staging");
     static constexpr int MISC = LAF + LAF_SZ;
     static constexpr int MUS = MISC;                        // S  : mean staging
@@ -1078,6 +1083,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                                             : (((l < D) && (!LY::COMPACT || (do_p && ok))) ? (LAF + l * ST) : DUMP);
 #pragma unroll
                     for (int c = NL; c < D; ++c) lrow[c - NL] = (M::MODEL == 0) ? col[c] : col[c] * MT<M>::aff_scale(c, pin);
+                    if constexpr (LY::LAF_PAD > 0) {   // see Layout16::LAF_PAD
+                        T* padp = (l == D) ? (LAF + D * ST) : DUMP;
+#pragma unroll
+                        for (int k = 0; k < LY::LAF_PAD; ++k) padp[k] = T(0);
+                    }
                 }
                 sigma_pair<T, M, LATE_XM>(mu_r, col, xp, xm);
             }

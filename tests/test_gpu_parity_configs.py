@@ -361,3 +361,14 @@ def test_model_buckets_equal_filter_order(spe, oracle, prec):
         m_o, c_o, s2 = oracle.pose_update(m_o, c_o, models[:k], cast(zz[:k]), cast(Q[:k]), threads=8)
         assert (s1 == 0).all() and (st_b[:k] == s2).all()
         assert max_abs(m_b[:k], m_o) <= tol and max_abs(c_b[:k], c_o) <= tol
+
+
+def test_randomised_scenarios_of_the_round3_launch_paths():
+    """tests/fuzz_round3.py: model-class buckets against filter order and the oracle (random class proportions, ragged sizes),
+    split launches + overlapped host uploads against single launches (random operation sequences, bit for bit)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_round3", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_round3.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert not fz.run(12, 3)

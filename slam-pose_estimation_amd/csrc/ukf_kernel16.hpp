@@ -37,6 +37,12 @@
 //    single launches, the per-cycle inputs come from device rings.
 //  * LDS per filter (Layout16): factor columns (stride 14) aliased by the delta table and the fp64 transposition,
 //    packed-covariance staging, affine factor rows, 56 scalars of mean / rotation / z, Q / store sink.
+//  * round 3: model-class buckets (KArgs::fidx_inputs: an indirect launch over a filter list grouped by update class, the
+//    per-call inputs indexed by the filter, -1 entries = padding); split launches (KArgs::item0: a direct launch as two half
+//    launches on two streams); the OrientationState fp64 slice trimmed to 11 workgroups per CU (Layout16::ORIENT64_TRIM,
+//    SINK_IN_NSH, LAF_PAD: every LDS scalar a kernel reads is one it wrote -- tests/test_gpu_lds_leftovers.py); and, default
+//    OFF because it measured slower, the fp64 Pose variant for four wavefronts per SIMD (UKFB_COMPACT64 + UKFB_LATE_XM:
+//    Layout16::COMPACT, the minus sigma point formed late -- DESIGN.md section 8).
 //
 // TOOLCHAIN NOTE (ROCm 7.2 hipcc, -O2/-O3): when this kernel needed VGPR spills / live-range
 // splits, the compiler placed the copies at the join label of a divergent `if` BEFORE the

@@ -13,6 +13,8 @@
  *  - the caller owns host buffers, the engine owns device buffers.
  *  - calls on one engine must come from one host thread at a time (the reference classes are
  *    boost::noncopyable and single-threaded, UnscentedKalmanFilter.hpp:16).
+ *  - every call works on its engine's device and leaves the calling thread's current HIP device as it
+ *    found it (one thread may drive engines on several devices, or share the thread with other HIP code).
  *  - work is enqueued on the engine's HIP stream; ukfb_sync() waits for it.  Functions that
  *    copy to host buffers synchronise themselves.
  *  - host-side numeric arrays are double and AoS ("host layout"):

@@ -33,6 +33,11 @@ thread_local bool g_wait_timed_out = false;   // the last bounded wait of this t
         }                                                  \
     } while (0)
 
+// the engine's device for the rest of the enclosing scope, the caller's device again afterwards (ukfb::DeviceScope)
+#define ON_DEVICE(dev)                                     \
+    ukfb::DeviceScope device_scope_(dev);                  \
+    HIP_TRY(device_scope_.err)
+
 // Waits for the engine's stream with the bounded polling wait (defined below).  A wait that gives up POISONS the engine:
 // work of unknown state is still queued, so every later call fails fast with UKFB_ERR_HIP, and ukfb_destroy neither waits
 // again nor frees device memory that a kernel in flight may still touch (the process is expected to exit non-zero).
@@ -176,7 +181,7 @@ int fill_scalar(ukfb_engine* e, void* dst_dev, size_t n, double value) {
 
 int launch(ukfb_engine* e, const ukfb::LaunchReq& r) {
     if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     if (r.wait_event) HIP_TRY(hipStreamWaitEvent(ukfb::main_stream(e), r.wait_event, 0));
     int rc;
     if (e->model == UKFB_MODEL_POSE)
@@ -723,7 +728,7 @@ static int create_impl(ukfb_engine** out, int model, int precision, int64_t capa
         g_last_error = "ukfb_create: no usable HIP device (the engine has no CPU fallback)";
         return UKFB_ERR_NO_DEVICE;
     }
-    HIP_TRY(hipSetDevice(device));
+    ON_DEVICE(device);
     ukfb_engine* e = new (std::nothrow) ukfb_engine();
     if (!e) return fail(UKFB_ERR_INVALID_ARG, "out of host memory");
     e->model = model;
@@ -763,7 +768,7 @@ int ukfb_layout_supported(int precision, int lanes_per_filter) {
 
 int ukfb_destroy(ukfb_engine* e) {
     if (!e) return UKFB_OK;
-    (void)hipSetDevice(e->device);
+    ukfb::DeviceScope device_scope(e->device);
     // bounded: a kernel that never finishes must not pin the host in the teardown either.  A poisoned engine (this wait or
     // an earlier one timed out) is abandoned as it is -- freeing memory under a kernel in flight would be worse than the leak
     (void)engine_wait(e);
@@ -832,7 +837,7 @@ int ukfb_describe(const ukfb_engine* e, int* model, int* precision, int64_t* cap
 
 int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* mu, const double* cov) {
     if (!range_ok(e, first, count) || !mu || !cov) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_initialize: bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     const int D = e->D, PK = e->PK;
     int rc = upload(e, e->mu, size_t(first) * e->S, mu, size_t(count) * e->S);
     if (rc) return rc;
@@ -861,7 +866,7 @@ int ukfb_initialize(ukfb_engine* e, int64_t first, int64_t count, const double* 
 
 int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised) {
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_get_state: bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     const int D = e->D, PK = e->PK;
     int rc;
     if (mu) {
@@ -895,13 +900,13 @@ int ukfb_get_state(ukfb_engine* e, int64_t first, int64_t count, double* mu, dou
 
 int ukfb_get_status(ukfb_engine* e, int64_t first, int64_t count, uint32_t* status) {
     if (!range_ok(e, first, count) || !status) return fail(UKFB_ERR_OUT_OF_RANGE, "ukfb_get_status: bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     return download_raw(e, e->status + first, status, size_t(count));
 }
 
 int ukfb_get_status_summary(ukfb_engine* e, uint32_t* or_of_all) {
     if (!e || !or_of_all) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     HIP_TRY(hipMemsetAsync(e->reduce_word, 0, sizeof(uint32_t), ukfb::main_stream(e)));
     const int blocks = int(std::min<int64_t>((e->cap + 255) / 256, 1024));
     hipLaunchKernelGGL(or_reduce_kernel, dim3(blocks), dim3(256), 0, ukfb::main_stream(e), e->status, e->cap, e->reduce_word);
@@ -911,13 +916,13 @@ int ukfb_get_status_summary(ukfb_engine* e, uint32_t* or_of_all) {
 
 int ukfb_set_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count, const int64_t* t_us) {
     if (!range_ok(e, first, count) || !t_us) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     return upload_raw(e, e->last_ts + first, t_us, size_t(count));
 }
 
 int ukfb_get_last_measurement_time(ukfb_engine* e, int64_t first, int64_t count, int64_t* t_us) {
     if (!range_ok(e, first, count) || !t_us) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     return download_raw(e, e->last_ts + first, t_us, size_t(count));
 }
 
@@ -931,7 +936,7 @@ int ukfb_device_views(ukfb_engine* e, void** mu_dev, void** cov_packed_dev, uint
 
 int ukfb_set_process_noise(ukfb_engine* e, const double* R) {
     if (!e || !R) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     const size_t dd = size_t(e->D) * e->D;
     e->Rn_host.assign(R, R + dd);
     {   // blocks [0:3,0:3] and [3:6,3:6] are the ones predictionStepImpl rotates (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85)
@@ -956,7 +961,7 @@ int ukfb_set_process_noise(ukfb_engine* e, const double* R) {
 
 int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t count, const double* R) {
     if (!range_ok(e, first, count) || !R) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     const size_t dd = size_t(e->D) * e->D;
     if (!e->Rn_per_filter) {
         void* big = nullptr;
@@ -977,7 +982,7 @@ int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t cou
 
 int ukfb_get_process_noise(ukfb_engine* e, int64_t filter, double* R) {
     if (!range_ok(e, filter, 1) || !R) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     const size_t dd = size_t(e->D) * e->D;
     return download(e, e->Rn, e->Rn_per_filter ? size_t(filter) * dd : 0, R, dd);
 }
@@ -987,7 +992,7 @@ int ukfb_pose_set_acceleration(ukfb_engine* e, int64_t first, int64_t count, con
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     if (acc_cov) {
         std::memcpy(e->acc_cov, acc_cov, 9 * sizeof(double));
         int rc = rebuild_racc(e);
@@ -1017,7 +1022,7 @@ int ukfb_orient_set_inputs(ukfb_engine* e, int64_t first, int64_t count, const d
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (e->model != UKFB_MODEL_ORIENT) return fail(UKFB_ERR_WRONG_MODEL, "Orient engines only");
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     // checkMeasurment (OrientationUKF.cpp:55,61): a non-finite row keeps the previously latched value
     auto latch = [&](void* dev, const double* src) -> int {
         bool all_finite = true;
@@ -1059,7 +1064,7 @@ int ukfb_orient_get_rotation_rate(ukfb_engine* e, int64_t first, int64_t count, 
     if (!e || !out) return UKFB_ERR_INVALID_ARG;
     if (e->model != UKFB_MODEL_ORIENT) return fail(UKFB_ERR_WRONG_MODEL, "Orient engines only");
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     // rotation_rate.mu - bias_gyro - q^-1 * earth_rotation (OrientationUKF.cpp:74-77): a read-out of
     // latched input and mean, not part of the predict/update arithmetic, evaluated host-side.
     std::vector<double> mu(size_t(count) * 14), w(size_t(count) * 3);
@@ -1091,7 +1096,7 @@ int ukfb_pose_export_body_states(ukfb_engine* e, int64_t first, int64_t count, d
     if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
     if (count == 0) return UKFB_OK;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     return e->prec == UKFB_F64 ? export_body_states<double>(e, first, count, out) : export_body_states<float>(e, first, count, out);
 }
 
@@ -1100,7 +1105,7 @@ int ukfb_pose_import_body_states(ukfb_engine* e, int64_t first, int64_t count, c
     if (e->model != UKFB_MODEL_POSE) return fail(UKFB_ERR_WRONG_MODEL, "Pose engines only");
     if (!range_ok(e, first, count)) return fail(UKFB_ERR_OUT_OF_RANGE, "bad range");
     if (count == 0) return UKFB_OK;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     return e->prec == UKFB_F64 ? import_body_states<double>(e, first, count, in) : import_body_states<float>(e, first, count, in);
 }
 
@@ -1123,7 +1128,7 @@ int ukfb_predict_dt_dev(ukfb_engine* e, const double* dt_dev) {
 
 int ukfb_predict_dt(ukfb_engine* e, const double* dt) {
     if (!e || !dt) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     int rc = upload_raw(e, e->dt_stage, dt, size_t(e->cap));
     if (rc) return rc;
     return ukfb_predict_dt_dev(e, e->dt_stage);
@@ -1139,7 +1144,7 @@ int ukfb_predict_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev) {
 
 int ukfb_predict_timestamps(ukfb_engine* e, const int64_t* ts_us) {
     if (!e || !ts_us) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     int rc = upload_raw(e, e->ts_stage, ts_us, size_t(e->cap));
     if (rc) return rc;
     return ukfb_predict_timestamps_dev(e, e->ts_stage);
@@ -1163,7 +1168,7 @@ int ukfb_update_dev(ukfb_engine* e, int meas_model_uniform, const int32_t* meas_
 int ukfb_update(ukfb_engine* e, int meas_model, const double* z, const double* Q, const uint8_t* active) {
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     if (!active) {   // the common form: samples uploaded on the copy stream while the previous kernel runs (see stage_cycle_inputs)
         Staged sg;
         const int src = stage_cycle_inputs(e, z, Q, size_t(e->cap) * 9, &sg);
@@ -1193,7 +1198,7 @@ int ukfb_update(ukfb_engine* e, int meas_model, const double* z, const double* Q
 
 int ukfb_update_mixed(ukfb_engine* e, const int32_t* meas_model, const double* z, const double* Q) {
     if (!e || !meas_model) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     int rc = stage_measurements(e, z, Q, meas_model, nullptr);
     if (rc) return rc;
     ukfb::LaunchReq r;
@@ -1225,7 +1230,7 @@ int ukfb_cycle_dev(ukfb_engine* e, double dt, int meas_model_uniform, const int3
         // launch over the grouped list: every wavefront is class-uniform, the sigma-point branch of the update is taken by
         // the wavefronts of that class only.
         if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
-        HIP_TRY(hipSetDevice(e->device));
+        ON_DEVICE(e->device);
         int64_t items = 0;
         const int rc = build_model_buckets(e, meas_model_dev, &items);
         if (rc) return rc;
@@ -1353,7 +1358,7 @@ int ukfb_cycle_multi(ukfb_engine* e, int cycles, double dt, int meas_model, cons
     if (cycles < 0) return fail(UKFB_ERR_INVALID_ARG, "cycles >= 0");
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
     if (cycles == 0) return UKFB_OK;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     // device rings of this call's samples, one slot per cycle: [z | Q | in_a | in_b]
     const size_t per = size_t(cycles) * size_t(e->cap);
     const size_t nz = per * 3, nq = per * 9, na = in_a ? per * 3 : 0, nb = in_b ? per * 3 : 0;
@@ -1397,7 +1402,7 @@ int ukfb_cycle_uniform_q_dev(ukfb_engine* e, double dt, int meas_model, const vo
 int ukfb_cycle_uniform_q(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q9) {
     if (!e || !z || !Q9) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     Staged sg;
     const int rc = stage_cycle_inputs(e, z, Q9, 9, &sg);
     if (rc) return rc;
@@ -1420,7 +1425,7 @@ int ukfb_cycle_uniform_q(ukfb_engine* e, double dt, int meas_model, const double
 int ukfb_update_uniform_q(ukfb_engine* e, int meas_model, const double* z, const double* Q9, const uint8_t* active) {
     if (!e || !z || !Q9) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     int rc = upload(e, e->z_stage, 0, z, size_t(e->cap) * 3);
     if (!rc) rc = upload(e, e->Q_stage, 0, Q9, 9);
     if (!rc && active) rc = upload_raw(e, e->active_stage, active, size_t(e->cap));
@@ -1438,7 +1443,7 @@ int ukfb_update_uniform_q(ukfb_engine* e, int meas_model, const double* z, const
 int ukfb_cycle(ukfb_engine* e, double dt, int meas_model, const double* z, const double* Q) {
     if (!e) return UKFB_ERR_INVALID_ARG;
     if (!meas_model_ok(e, meas_model)) return fail(UKFB_ERR_WRONG_MODEL, "measurement model id not valid for this engine");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     Staged sg;
     const int rc = stage_cycle_inputs(e, z, Q, size_t(e->cap) * 9, &sg);
     if (rc) return rc;
@@ -1472,7 +1477,7 @@ int ukfb_cycle_timestamps_dev(ukfb_engine* e, const int64_t* ts_us_dev, const in
 
 int ukfb_cycle_timestamps(ukfb_engine* e, const int64_t* ts_us, const int32_t* meas_model, const double* z, const double* Q) {
     if (!e || !ts_us || !meas_model) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     int rc = stage_measurements(e, z, Q, meas_model, nullptr);
     if (rc) return rc;
     rc = upload_raw(e, e->ts_stage, ts_us, size_t(e->cap));
@@ -1624,7 +1629,7 @@ int ukfb_process_events(ukfb_engine* e, int64_t n_events, const int64_t* filter,
                         const int32_t* meas_model, const double* z, const double* Q, uint32_t* status_or, int64_t* rounds) {
     if (!e || n_events < 0 || n_events > 0x7fffffff || (n_events > 0 && (!filter || !ts_us || !meas_model || !z || !Q)))
         return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events: bad argument");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     if (status_or) *status_or = 0;
     if (rounds) *rounds = 0;
     if (n_events == 0) return UKFB_OK;
@@ -1657,7 +1662,7 @@ int ukfb_process_events_dev(ukfb_engine* e, int64_t n_events, const int64_t* fil
     if (!e || n_events < 0 || n_events > 0x7fffffff ||
         (n_events > 0 && (!filter_dev || !ts_us_dev || !meas_model_dev || !z_dev || !Q_dev)))
         return fail(UKFB_ERR_INVALID_ARG, "ukfb_process_events_dev: bad argument");
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     if (status_or) *status_or = 0;
     if (rounds) *rounds = 0;
     if (n_events == 0) return UKFB_OK;
@@ -1685,14 +1690,14 @@ int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capa
 
 int ukfb_timer_begin(ukfb_engine* e) {
     if (!e) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     HIP_TRY(hipEventRecord(e->ev0, ukfb::main_stream(e)));
     return UKFB_OK;
 }
 
 int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms) {
     if (!e || !elapsed_ms) return UKFB_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     if (e->poisoned) return fail(UKFB_ERR_HIP, "engine poisoned by an earlier wait that timed out (UKFB_WAIT_TIMEOUT_S)");
     HIP_TRY(hipEventRecord(e->ev1, ukfb::main_stream(e)));
     {

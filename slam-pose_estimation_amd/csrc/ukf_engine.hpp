@@ -137,6 +137,27 @@ int launch_orient_f32(ukfb_engine* e, const LaunchReq& r);
 void set_error(const char* what, hipError_t err);
 void set_error_text(const std::string& text);   // what ukfb_last_error() returns on this thread
 
+// Every entry point works on its engine's device and hands the calling thread back on the device it came with: a host that
+// drives several engines from one thread (ukfb_group_*), or shares the thread with another HIP user, keeps its own notion of
+// "current device".  Nothing is switched (one thread-local read) when the caller already is on the engine's device.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev) {
+        int cur = -1;
+        err = hipGetDevice(&cur);
+        if (err == hipSuccess && cur != dev) {
+            err = hipSetDevice(dev);
+            if (err == hipSuccess) prev = cur;
+        }
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // The engine's stream for anything but a split launch: first makes it wait for the second half of the last split launch.
 inline hipStream_t main_stream(ukfb_engine* e) {
     if (e->split_pending) {

@@ -95,7 +95,7 @@ void release_gather(ukfb_group* g) {
         if (g->comms[r]) (void)rccl().CommDestroy(g->comms[r]);
     g->comms.clear();
     for (size_t r = 0; r < g->send_pad.size(); ++r) {
-        (void)hipSetDevice(g->devices[r]);
+        ukfb::DeviceScope on_device(g->devices[r]);
         if (g->send_pad[r]) (void)hipFree(g->send_pad[r]);
         if (g->recv_pad[r]) (void)hipFree(g->recv_pad[r]);
     }
@@ -402,7 +402,8 @@ int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
         g->send_pad.assign(n, nullptr);
         g->recv_pad.assign(n, nullptr);
         for (size_t r = 0; r < n; ++r) {
-            if (hipSetDevice(g->devices[r]) != hipSuccess || hipMalloc(&g->send_pad[r], pad_bytes) != hipSuccess ||
+            ukfb::DeviceScope on_device(g->devices[r]);
+            if (on_device.err != hipSuccess || hipMalloc(&g->send_pad[r], pad_bytes) != hipSuccess ||
                 hipMalloc(&g->recv_pad[r], pad_bytes * n) != hipSuccess || hipMemset(g->send_pad[r], 0, pad_bytes) != hipSuccess) {
                 release_gather(g);
                 return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging allocation failed");
@@ -413,7 +414,8 @@ int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
     std::vector<hipStream_t> streams(n);
     for (size_t r = 0; r < n; ++r) {
         ukfb_engine* e = g->engines[r];
-        if (hipSetDevice(g->devices[r]) != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
+        ukfb::DeviceScope on_device(g->devices[r]);
+        if (on_device.err != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
         streams[r] = ukfb::main_stream(e);
         if (hipMemcpyAsync(g->send_pad[r], e->mu, size_t(g->count[r]) * row, hipMemcpyDeviceToDevice, streams[r]) != hipSuccess)
             return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging copy failed");
@@ -426,7 +428,8 @@ int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
     if (st != ncclSuccess || st2 != ncclSuccess)
         return gfail(UKFB_ERR_HIP, std::string("ncclAllGather: ") + rc.GetErrorString(st != ncclSuccess ? st : st2));
     for (size_t r = 0; r < n; ++r) {
-        if (hipSetDevice(g->devices[r]) != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
+        ukfb::DeviceScope on_device(g->devices[r]);
+        if (on_device.err != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
         for (size_t s = 0; s < n; ++s)
             if (hipMemcpyAsync(static_cast<char*>(out_dev[r]) + size_t(g->first[s]) * row,
                                static_cast<const char*>(g->recv_pad[r]) + s * pad_bytes, size_t(g->count[s]) * row,

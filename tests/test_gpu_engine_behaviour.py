@@ -220,9 +220,9 @@ def test_per_filter_process_noise_and_read_back(spe, oracle):
     assert max_abs(m, m_o) <= 1e-9 and max_abs(c, c_o) <= 1e-9
 
 
-@pytest.mark.parametrize("prec,n", [(0, 65536), (1, 1048576)])
+@pytest.mark.parametrize("prec,n", [(0, 65536), (1, 1048576), (0, 1048576)])
 def test_full_size_properties(spe, prec, n):
-    """BASELINE configs 2 (65 536 fp64) and 3 (1 048 576 fp32): properties that need no oracle run.
+    """BASELINE configs 2 (65 536 fp64) and 3 (1 048 576 fp32) and the metric's own batch (1 048 576 fp64): properties that need no oracle run.
     (a) a batch equals its two halves run separately, bit for bit (no coupling between filters, ragged
     tail handled); (b) covariances stay symmetric positive definite, quaternions unit; (c) an update
     with an uninformative measurement (Q -> huge) is the identity."""

@@ -1,7 +1,8 @@
 """No kernel of the engine may depend on LDS it did not write itself.
 
 tests/cpp/lds_poison.hip fills the LDS of every CU with a bit pattern; the engine then runs the launches the BASELINE
-configurations use (fused cycle, separate prediction and update, multi-cycle, per-filter models) and must give the SAME BITS
+configurations use (fused cycle, separate prediction and update, multi-cycle, per-filter models, event rounds = the
+indirect kernel) and must give the SAME BITS
 after a NaN pattern, an Inf pattern and zeros.  Found in round 3 by tests/fuzz_parity.py as a box-dependent Cholesky failure:
 an alignment pad between two LDS regions was read as "leftover times the table's exact-zero row" -- NaN whenever the leftover
 of an earlier kernel happened to be NaN or Inf (Layout16::LAF_PAD in ukf_kernel16.hpp)."""
@@ -65,8 +66,18 @@ def _run(spe, model, prec, G, n=4099):
         e.cycle_multi_dev(2, 0.01, spe.MEAS_ORIENT_BODYVEL3, z_t.reshape(2, n, 3), Q_t.reshape(2, n, 9), 2, 0)
     m, c, _ = e.state()
     st = e.status()
+    # the indirect instantiation (event rounds): two samples for every third filter, a third one for some, any arrival order
+    rng = np.random.default_rng(5)
+    f_ev = np.concatenate([np.arange(0, n, 3), np.arange(0, n, 3), np.arange(0, n, 7)])
+    t_ev = np.concatenate([np.full(len(range(0, n, 3)), 1_010_000), np.full(len(range(0, n, 3)), 1_020_000), np.full(len(range(0, n, 7)), 1_030_000)])
+    perm = rng.permutation(f_ev.size)
+    f_ev, t_ev = f_ev[perm], t_ev[perm]
+    model_ev = spe.MEAS_POS3 if model == "pose" else spe.MEAS_ORIENT_BODYVEL3
+    e.process_events(f_ev, t_ev, np.full(f_ev.size, model_ev, dtype=np.int32), z[f_ev], Q[f_ev])
+    m2, c2, _ = e.state()
+    st2 = e.status()
     e.close()
-    return m, c, st
+    return m, c, st, m2, c2, st2
 
 
 @pytest.mark.parametrize("G", [16, 64])      # the tuned layout and the one-wavefront-per-filter ablation (fp32 in the shipped library)
@@ -77,9 +88,11 @@ def test_results_do_not_depend_on_lds_leftovers(spe, model, prec, G):
     ref = None
     for pat in PATTERNS:
         assert poison(pat) == 0
-        m, c, st = _run(spe, model, prec, G)
+        got = _run(spe, model, prec, G)
+        m, c, st, m2, c2, _ = got
         assert np.isfinite(m).all() and np.isfinite(c).all() and (st == 0).all(), (model, prec, hex(pat))
+        assert np.isfinite(m2).all() and np.isfinite(c2).all() and not np.array_equal(m, m2), (model, prec, hex(pat))
         if ref is None:
-            ref = (m, c, st)
+            ref = got
         else:
-            assert np.array_equal(m, ref[0]) and np.array_equal(c, ref[1]) and (st == ref[2]).all(), (model, prec, hex(pat))
+            assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (model, prec, hex(pat))

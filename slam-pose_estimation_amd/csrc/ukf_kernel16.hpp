@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 // (OrientationState kernels only: in the Pose kernels the two extra branches cost the acceleration-branch
                 // headline 0.6 % through code placement alone, same-box A/B)
                 if constexpr (M::MODEL != 0)
-                    noise_plain = a.noise_iso != 0 && wave_all(m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(UKFB_ISO_TOL_F32)));
+                    noise_plain = a.noise_iso != 0 && wave_all(!do_p || m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(UKFB_ISO_TOL_F32)));
                 need_rot = !noise_plain && (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc)));
                 if constexpr (!LY::COMPACT) {
                     if (need_rot) {
@@ -1255,7 +1255,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             T rpl[3] = {T(0), T(0), T(0)}, rml[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)};
             bool have_last = false;   // wave-uniform
             {
-                bool active = n2 > a.mean_tol * a.mean_tol;
+                bool active = pc && n2 > a.mean_tol * a.mean_tol;   // (rows that commit nothing never keep the wavefront iterating)
                 int it = 0;
                 if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
                 while (wave_any(active)) {
@@ -1307,7 +1307,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 if (rebase) {
                     const T tp = rpl[0] * rpl[0] + rpl[1] * rpl[1] + rpl[2] * rpl[2];
                     const T tm = rml[0] * rml[0] + rml[1] * rml[1] + rml[2] * rml[2];
-                    rebase = wave_all(tp <= T(2.25) && tm <= T(2.25) && a2 <= T(1e-12));
+                    // (a row whose prediction is not committed -- uninitialised, gated out, failed factorisation: NaN deltas --
+                    // has no say in what its wave-mates do)
+                    rebase = wave_all(!pc || (tp <= T(2.25) && tm <= T(2.25) && a2 <= T(1e-12)));
                 }
                 if (rebase) {
                     so3_rebase_small(rpl, al, a2, rp);

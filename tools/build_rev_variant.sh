@@ -10,11 +10,13 @@ git -C $root worktree add -f --detach $wt $rev > /dev/null 2>&1
 src=$wt/slam-pose_estimation_amd/csrc
 out=$root/slam-pose_estimation_amd/lib/ab; obj=$out/obj_$name; mkdir -p $obj
 pids=""
-for tu in ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize ${REV_FLAGS--mllvm -disable-machine-licm} -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.log &
+tus="ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32"
+[ -f $src/ukf_group.hip ] && tus="$tus ukf_group"     # (device groups: round 3 on)
+for tu in $tus; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -DUKFB_GENERIC_F64=0 ${REV_FLAGS--mllvm -disable-machine-licm} -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.log &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o -ldl
 rm -rf $obj; git -C $root worktree remove --force $wt
 echo "built $out/$name.so from $rev"

@@ -46,7 +46,7 @@ def aniso(rng, R):
     return R
 
 
-EXPLAINED = [0]    # failing fp32 launches whose error the float instantiation of the oracle shares (within 2x)
+EXPLAINED = [0]    # failing fp32 launches whose error the float instantiation of the oracle shares (within 4x)
 
 
 def compare(tag, prec, m_g, c_g, st_g, m_o, c_o, st_o, fails, ctx, alt=None):
@@ -67,10 +67,11 @@ def compare(tag, prec, m_g, c_g, st_g, m_o, c_o, st_o, fails, ctx, alt=None):
         if prec == 1 and alt is not None and ok_state.all():
             m_a, c_a = alt()
             fm, fc = max_abs(m_a, m_o), max_abs(c_a, c_o)
-            shared = em <= 2.0 * max(fm, 1e-7) and ec <= 2.0 * max(fc, 1e-7)
+            # same order of magnitude (two fp32 evaluation orders of an ill-conditioned step differ by small factors, not by decades)
+            shared = em <= 4.0 * max(fm, 1e-7) and ec <= 4.0 * max(fc, 1e-7)
             EXPLAINED[0] += 1 if shared else 0
             fails[-1] += (f" | float oracle on the same launch: max|dmu| {fm:.3e} max|dcov| {fc:.3e} -> "
-                          + ("fp32 arithmetic of the algorithm itself (the engine is within 2x of it)" if shared else "NOT explained by fp32 arithmetic"))
+                          + (f"fp32 arithmetic of the algorithm itself (engine / float oracle = {em / max(fm, 1e-30):.2f} on the mean, {ec / max(fc, 1e-30):.2f} on the covariance)" if shared else "NOT explained by fp32 arithmetic (engine more than 4x the float oracle)"))
         return False
     return True
 

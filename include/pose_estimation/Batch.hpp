@@ -158,6 +158,20 @@ public:
     void cycle(double delta_t, int model, const double* z, const double* Q) { check(ukfb_group_cycle(group, delta_t, model, z, Q)); }
     /** samples already resident on the devices: z_dev[r] / Q_dev[r] on shard r's device, engine precision */
     void cycleDev(double delta_t, int model, const void* const* z_dev, const void* const* Q_dev) { check(ukfb_group_cycle_dev(group, delta_t, model, z_dev, Q_dev)); }
+    /** per-filter model ids resident on the devices: meas_model_dev[r] = int32 [filters of shard r] */
+    void cycleMixedDev(double delta_t, const int32_t* const* meas_model_dev, const void* const* z_dev, const void* const* Q_dev)
+    {
+        check(ukfb_group_cycle_mixed_dev(group, delta_t, meas_model_dev, z_dev, Q_dev));
+    }
+    /** fused predictionStepFromSampleTime(ts[i]) + integrateMeasurement(model[i]) per filter, host arrays over the whole batch */
+    void cycleFromSampleTimes(const int64_t* ts_us, const int32_t* model, const double* z, const double* Q) { check(ukfb_group_cycle_timestamps(group, ts_us, model, z, Q)); }
+    /** time-ordered asynchronous stream over the sharded batch (filter indices in batch numbering); returns the launches of the shard that needed most */
+    int64_t processEvents(int64_t n_events, const int64_t* filter, const int64_t* ts_us, const int32_t* model, const double* z, const double* Q)
+    {
+        int64_t rounds = 0;
+        check(ukfb_group_process_events(group, n_events, filter, ts_us, model, z, Q, NULL, &rounds));
+        return rounds;
+    }
     void bindAccelerationsDev(const void* const* acc_mu_dev) { check(ukfb_group_pose_bind_acceleration_dev(group, acc_mu_dev)); }
     /** RCCL all-gather: out_dev[r] ([total][13], engine precision, on shard r's device) receives every filter's mean */
     void gatherMeans(void* const* out_dev) { check(ukfb_group_gather_means(group, out_dev)); }

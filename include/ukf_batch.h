@@ -342,6 +342,17 @@ int ukfb_group_cycle_dev(ukfb_group* g, double dt, int meas_model, const void* c
 int ukfb_group_cycle_multi_dev(ukfb_group* g, int cycles, double dt, int meas_model, int slots, int first_slot,
                                const void* const* in_a_dev, const void* const* in_b_dev, const void* const* z_dev,
                                const void* const* Q_dev);
+/* per-filter model ids resident on the devices (ukfb_cycle_dev with meas_model_dev), one pointer per shard */
+int ukfb_group_cycle_mixed_dev(ukfb_group* g, double dt, const int32_t* const* meas_model_dev, const void* const* z_dev,
+                               const void* const* Q_dev);
+/* ukfb_cycle_timestamps over the whole batch: host arrays [total] in batch numbering */
+int ukfb_group_cycle_timestamps(ukfb_group* g, const int64_t* ts_us, const int32_t* meas_model, const double* z, const double* Q);
+/* ukfb_process_events over the whole batch: `filter` in batch numbering, any arrival order.  Events are routed to the shard
+ * that owns their filter (stable: per filter the arrival order survives), the shards order and apply their events
+ * concurrently (one host thread per shard for the duration of the call).  rounds = the launches of the shard that needed most;
+ * statuses as ukfb_process_events leaves them (a filter without samples: 0). */
+int ukfb_group_process_events(ukfb_group* g, int64_t n_events, const int64_t* filter, const int64_t* ts_us,
+                              const int32_t* meas_model, const double* z, const double* Q, uint32_t* status_or, int64_t* rounds);
 int ukfb_group_sync(ukfb_group* g);
 /* HIP-event timing on every shard's stream; elapsed_ms_max = the slowest shard, elapsed_ms_per_shard [shards] may be NULL */
 int ukfb_group_timer_begin(ukfb_group* g);

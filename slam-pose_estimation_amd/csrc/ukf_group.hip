@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -341,6 +342,99 @@ int ukfb_group_update(ukfb_group* g, int meas_model, const double* z, const doub
         const int rc = ukfb_update(g->engines[r], meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9, nullptr);
         if (rc) return efail(rc);
     }
+    return UKFB_OK;
+}
+
+// per-filter model ids on the devices (the mixed asynchronous stream of BASELINE config 5, one pointer per shard)
+int ukfb_group_cycle_mixed_dev(ukfb_group* g, double dt, const int32_t* const* meas_model_dev, const void* const* z_dev,
+                               const void* const* Q_dev) {
+    if (!g || !meas_model_dev || !z_dev || !Q_dev) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const int rc = ukfb_cycle_dev(g->engines[r], dt, 0, meas_model_dev[r], z_dev[r], Q_dev[r]);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+// fused predictionStepFromSampleTime + integrateMeasurement per filter, host arrays over the whole batch
+int ukfb_group_cycle_timestamps(ukfb_group* g, const int64_t* ts_us, const int32_t* meas_model, const double* z, const double* Q) {
+    if (!g || !ts_us || !meas_model) return UKFB_ERR_INVALID_ARG;
+    for (size_t r = 0; r < g->engines.size(); ++r) {
+        const size_t o = size_t(g->first[r]);
+        const int rc = ukfb_cycle_timestamps(g->engines[r], ts_us + o, meas_model + o, z ? z + o * 3 : nullptr, Q ? Q + o * 9 : nullptr);
+        if (rc) return efail(rc);
+    }
+    return UKFB_OK;
+}
+
+// The time-ordered asynchronous stream over a sharded batch: events are routed to the shard that owns their filter (a
+// stable partition: per filter the arrival order survives, which is all the ordering the stream has), every shard then
+// orders and applies its own events.  The shards run concurrently, one host thread each -- a shard's call returns only
+// when the host knows its number of rounds.
+int ukfb_group_process_events(ukfb_group* g, int64_t n_events, const int64_t* filter, const int64_t* ts_us, const int32_t* meas_model,
+                              const double* z, const double* Q, uint32_t* status_or, int64_t* rounds) {
+    if (!g || n_events < 0 || n_events > 0x7fffffff || (n_events > 0 && (!filter || !ts_us || !meas_model || !z || !Q)))
+        return gfail(UKFB_ERR_INVALID_ARG, "ukfb_group_process_events: bad argument");
+    if (status_or) *status_or = 0;
+    if (rounds) *rounds = 0;
+    if (n_events == 0) return UKFB_OK;
+    const size_t n = g->engines.size();
+    struct Part {
+        std::vector<int64_t> f, t;
+        std::vector<int32_t> m;
+        std::vector<double> z, q;
+        uint32_t st = 0;
+        int64_t rounds = 0;
+        int rc = UKFB_OK;
+        std::string err;
+    };
+    std::vector<Part> parts(n);
+    for (int64_t i = 0; i < n_events; ++i) {
+        const int64_t f = filter[i];
+        if (f < 0 || f >= g->total) return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_process_events: filter index outside the batch");
+        const size_t r = size_t(std::upper_bound(g->first.begin(), g->first.end(), f) - g->first.begin()) - 1;
+        Part& p = parts[r];
+        p.f.push_back(f - g->first[r]);
+        p.t.push_back(ts_us[i]);
+        p.m.push_back(meas_model[i]);
+        p.z.insert(p.z.end(), z + size_t(i) * 3, z + size_t(i) * 3 + 3);
+        p.q.insert(p.q.end(), Q + size_t(i) * 9, Q + size_t(i) * 9 + 9);
+    }
+    const auto run = [&](size_t r) {
+        Part& p = parts[r];
+        ukfb_engine* e = g->engines[r];
+        if (p.f.empty()) {
+            // no sample for this shard: what the call does to a filter without samples -- a fresh, empty status word
+            ukfb::DeviceScope on_device(e->device);
+            if (on_device.err != hipSuccess ||
+                hipMemsetAsync(e->status, 0, size_t(e->cap) * sizeof(uint32_t), ukfb::main_stream(e)) != hipSuccess) {
+                p.rc = UKFB_ERR_HIP;
+                p.err = "ukfb_group_process_events: status reset failed";
+            }
+            return;
+        }
+        p.rc = ukfb_process_events(e, int64_t(p.f.size()), p.f.data(), p.t.data(), p.m.data(), p.z.data(), p.q.data(), &p.st, &p.rounds);
+        if (p.rc) p.err = ukfb_last_error();   // (the text is per thread)
+    };
+    size_t busy = 0;
+    for (const Part& p : parts) busy += p.f.empty() ? 0 : 1;
+    if (busy <= 1) {
+        for (size_t r = 0; r < n; ++r) run(r);
+    } else {
+        std::vector<std::thread> workers;
+        for (size_t r = 1; r < n; ++r) workers.emplace_back(run, r);
+        run(0);
+        for (std::thread& w : workers) w.join();
+    }
+    uint32_t st = 0;
+    int64_t rd = 0;
+    for (const Part& p : parts) {
+        if (p.rc) return gfail(p.rc, p.err);
+        st |= p.st;
+        rd = std::max(rd, p.rounds);
+    }
+    if (status_or) *status_or = st;
+    if (rounds) *rounds = rd;   // launches of the shard that needed most
     return UKFB_OK;
 }
 

@@ -54,7 +54,8 @@ EXPORTS = [
     "ukfb_group_get_status_summary", "ukfb_group_set_process_noise", "ukfb_group_pose_set_acceleration",
     "ukfb_group_orient_set_params", "ukfb_group_orient_set_inputs", "ukfb_group_predict", "ukfb_group_update",
     "ukfb_group_cycle", "ukfb_group_pose_bind_acceleration_dev", "ukfb_group_orient_bind_inputs_dev",
-    "ukfb_group_cycle_dev", "ukfb_group_cycle_multi_dev", "ukfb_group_sync", "ukfb_group_timer_begin",
+    "ukfb_group_cycle_dev", "ukfb_group_cycle_multi_dev", "ukfb_group_cycle_mixed_dev", "ukfb_group_cycle_timestamps",
+    "ukfb_group_process_events", "ukfb_group_sync", "ukfb_group_timer_begin",
     "ukfb_group_timer_end", "ukfb_group_gather_means",
 ]
 BODY_STATE_SCALARS = 49
@@ -607,6 +608,32 @@ class UKFGroup:
         _chk(self._lib.ukfb_group_cycle_multi_dev(self._g, C.c_int(cycles), C.c_double(dt), C.c_int(meas_model), C.c_int(slots),
                                                   C.c_int(first_slot), self._ptrs(in_a_devs), self._ptrs(in_b_devs),
                                                   self._ptrs(z_devs), self._ptrs(Q_devs)), "ukfb_group_cycle_multi_dev")
+
+    def cycle_mixed_dev(self, dt: float, meas_model_devs, z_devs, Q_devs):
+        """per-filter model ids resident on the devices (int32, one array per shard)"""
+        _chk(self._lib.ukfb_group_cycle_mixed_dev(self._g, C.c_double(dt), self._ptrs(meas_model_devs), self._ptrs(z_devs),
+                                                  self._ptrs(Q_devs)), "ukfb_group_cycle_mixed_dev")
+
+    def cycle_timestamps(self, ts_us, meas_model, z, Q):
+        t = np.ascontiguousarray(ts_us, dtype=np.int64).reshape(self.total)
+        m = np.ascontiguousarray(meas_model, dtype=np.int32).reshape(self.total)
+        z = _f64(z, (self.total, 3)); Q = _f64(Q, (self.total, 3, 3))
+        _chk(self._lib.ukfb_group_cycle_timestamps(self._g, t.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                   m.ctypes.data_as(C.POINTER(C.c_int32)), _pd(z), _pd(Q)), "ukfb_group_cycle_timestamps")
+
+    def process_events(self, filter_index, ts_us, meas_model, z, Q):
+        """Time-ordered asynchronous stream over the sharded batch (filter indices in batch numbering, any arrival order).
+        Returns (status_or, rounds of the shard that needed most)."""
+        f = np.ascontiguousarray(filter_index, dtype=np.int64).reshape(-1)
+        n = f.size
+        t = np.ascontiguousarray(ts_us, dtype=np.int64).reshape(n)
+        m = np.ascontiguousarray(meas_model, dtype=np.int32).reshape(n)
+        z = _f64(z, (n, 3)); Q = _f64(Q, (n, 3, 3))
+        st, rounds = C.c_uint32(0), C.c_int64(0)
+        _chk(self._lib.ukfb_group_process_events(self._g, C.c_int64(n), f.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                 t.ctypes.data_as(C.POINTER(C.c_int64)), m.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 _pd(z), _pd(Q), C.byref(st), C.byref(rounds)), "ukfb_group_process_events")
+        return int(st.value), int(rounds.value)
 
     def sync(self):
         _chk(self._lib.ukfb_group_sync(self._g), "ukfb_group_sync")

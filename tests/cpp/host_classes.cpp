@@ -170,10 +170,27 @@ int main()
         single.setAccelerations(0, NS, am, acov); sharded.setAccelerations(0, NS, am, acov);
         single.cycle(0.01, UKFB_MEAS_POS3, zz, QQ); sharded.cycle(0.01, UKFB_MEAS_POS3, zz, QQ);
         single.predictionStep(0.02); sharded.predictionStep(0.02);
+        // the asynchronous stream over both shards: filter 5 has two samples that arrive out of order, filters 1 and 6 one each
+        {
+            const int64_t ef[4] = {5, 1, 6, 5}, et[4] = {2030000, 2010000, 2010000, 2010000};
+            const int32_t em[4] = {UKFB_MEAS_POS3, UKFB_MEAS_POS3, -1, UKFB_MEAS_POS3};
+            double ez[12], eq[36];
+            for (int j = 0; j < 4; ++j) {
+                for (int k = 0; k < 3; ++k) ez[j * 3 + k] = zz[ef[j] * 3 + k] + 0.001 * (j + 1);
+                for (int k = 0; k < 9; ++k) eq[j * 9 + k] = QQ[k];
+            }
+            const int64_t r1 = single.processEvents(4, ef, et, em, ez, eq), r2 = sharded.processEvents(4, ef, et, em, ez, eq);
+            if (r1 != 2 || r2 != 2) std::printf("\"sharded_event_rounds\": [%lld, %lld],\n", (long long)r1, (long long)r2);
+        }
         sharded.sync();
         double ma[NS * 13], ca[NS * 144], mb[NS * 13], cb[NS * 144];
         single.getCurrentStates(0, NS, ma, ca); sharded.getCurrentStates(0, NS, mb, cb);
-        bool same = sharded.shards() == 2 && sharded.statusSummary() == 0u;
+        uint32_t st_single = 0u;
+        {
+            const std::vector<uint32_t> st = single.status();
+            for (size_t k = 0; k < st.size(); ++k) st_single |= st[k];
+        }
+        bool same = sharded.shards() == 2 && sharded.statusSummary() == st_single;
         double moved = 0.0;
         for (int k = 0; k < NS * 13; ++k) { same = same && ma[k] == mb[k]; moved = std::fmax(moved, std::fabs(ma[k] - ms[k])); }
         for (int k = 0; k < NS * 144; ++k) same = same && ca[k] == cb[k];

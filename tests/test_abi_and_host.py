@@ -162,6 +162,9 @@ def test_group_entry_points_without_a_gpu(spe):
     assert lib.ukfb_group_size(null) == -1
     assert lib.ukfb_group_sync(null) != 0 and lib.ukfb_group_cycle_dev(null, C.c_double(0.01), 0, null, null) != 0
     assert lib.ukfb_group_gather_means(null, null) != 0 and lib.ukfb_group_destroy(null) == 0
+    assert lib.ukfb_group_cycle_mixed_dev(null, C.c_double(0.01), null, null, null) != 0
+    assert lib.ukfb_group_cycle_timestamps(null, null, null, null, null) != 0
+    assert lib.ukfb_group_process_events(null, C.c_int64(0), null, null, null, null, null, null, null) != 0
     if not torch.cuda.is_available():
         with pytest.raises(spe.UkfbError) as ei:
             spe.UKFGroup(spe.MODEL_POSE, spe.F64, 64, [0, 0])

@@ -120,3 +120,61 @@ def test_orientation_group_equals_the_unsharded_batch(spe):
     assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and grp.status_summary() == one.status_summary() == 0
     assert max_abs(m1, mu) > 1e-4 and [sh["count"] for sh in grp.shards] == [344, 344, 343]
     grp.close(); one.close()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_group_event_stream_timestamps_and_per_filter_models(spe, prec):
+    """The asynchronous side of the boundary over a sharded batch: ukfb_group_process_events (events routed to the shard that
+    owns their filter, shards run concurrently on host threads), ukfb_group_cycle_timestamps and ukfb_group_cycle_mixed_dev
+    -- a 3-shard group on device 0 against ONE engine over the same filters, bit for bit, statuses included.  The third
+    shard gets no event at all (its filters must read status 0 afterwards, as the filters without samples of one engine do)."""
+    import torch
+    s = spe.synth
+    rng = np.random.default_rng(17)
+    n = 1531
+    mu, cov, ring, tdt = _inputs(spe, n, prec)
+    one = spe.BatchPoseUKF(n, precision=prec)
+    grp = spe.UKFGroup(spe.MODEL_POSE, prec, n, [0, 0, 0])
+    one.initialize(mu, cov); grp.initialize(mu, cov)
+    # leave a status behind everywhere (INACTIVE for the filters whose model is negative) that the event call must replace
+    models = s.pose_mixed_models(n, 2)
+    zz = s.pose_measurement_for_model(mu, models, ring[0][1] - mu[:, :3])
+    dev = lambda x, t=tdt: torch.from_numpy(np.ascontiguousarray(x.reshape(x.shape[0], -1))).to("cuda", t)   # noqa: E731
+    m_t, z_t, Q_t = torch.from_numpy(models).cuda(), dev(zz), dev(ring[0][2])
+    cuts = [(sh["first"], sh["first"] + sh["count"]) for sh in grp.shards]
+    m_s, z_s, Q_s = ([t[lo:hi].contiguous() for lo, hi in cuts] for t in (m_t, z_t, Q_t))
+    torch.cuda.synchronize()
+    one.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t, meas_model_dev=m_t); grp.cycle_mixed_dev(0.01, m_s, z_s, Q_s)
+    grp.sync(); one.sync()
+    assert (one.status() == grp.status()).all() and (one.status() & spe.ST_INACTIVE).any()
+    # events: 0..4 samples per filter of the first two shards, shuffled; none for the last shard
+    last_first = grp.shards[2]["first"]
+    f_ev, t_ev = [], []
+    for f in range(last_first):
+        k = int(rng.integers(0, 5))
+        f_ev += [f] * k
+        t_ev += list(1_000_000 + np.cumsum(rng.integers(1_000, 40_000, size=k)))
+    f_ev, t_ev = np.array(f_ev), np.array(t_ev, dtype=np.int64)
+    perm = rng.permutation(f_ev.size)
+    f_ev, t_ev = f_ev[perm], t_ev[perm]
+    mod_ev = rng.choice(np.array([-1, 0, 4, 3], dtype=np.int32), size=f_ev.size)
+    z_ev = s.pose_measurement_for_model(mu[f_ev], np.maximum(mod_ev, 0), 0.05 * rng.normal(size=(f_ev.size, 3)))
+    Q_ev = np.tile(0.01 * np.eye(3), (f_ev.size, 1, 1))
+    r1 = one.process_events(f_ev, t_ev, mod_ev, z_ev, Q_ev)
+    rg = grp.process_events(f_ev, t_ev, mod_ev, z_ev, Q_ev)
+    assert r1 == rg and rg[1] == 4
+    m1, c1, _ = one.state(); mg, cg, _ = grp.state()
+    assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and (one.status() == grp.status()).all()
+    assert (grp.status(last_first) == 0).all() and max_abs(m1[:last_first], mu[:last_first]) > 1e-3
+    # an index outside the batch is refused before anything is launched
+    with pytest.raises(spe.UkfbError):
+        grp.process_events([n], [1], [0], np.zeros((1, 3)), np.eye(3)[None])
+    # per-filter sample times over the whole batch
+    ts = np.where(rng.random(n) < 0.8, 2_000_000 + rng.integers(0, 30_000, size=n), -1).astype(np.int64)
+    mod = rng.choice(np.array([-1, 0, 4], dtype=np.int32), size=n)
+    zt = s.pose_measurement_for_model(mu, np.maximum(mod, 0), 0.05 * rng.normal(size=(n, 3)))
+    Qt = np.tile(0.02 * np.eye(3), (n, 1, 1))
+    one.cycle_timestamps(ts, mod, zt, Qt); grp.cycle_timestamps(ts, mod, zt, Qt)
+    m1, c1, _ = one.state(); mg, cg, _ = grp.state()
+    assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and (one.status() == grp.status()).all()
+    grp.close(); one.close()

@@ -17,6 +17,6 @@ for tu in $tus; do
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o -ldl -pthread
 rm -rf $obj; git -C $root worktree remove --force $wt
 echo "built $out/$name.so from $rev"

@@ -23,6 +23,6 @@ for tu in ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_laun
 done
 for p in $pids; do wait $p; done
 python3 $root/tools/check_resources.py $obj/ukf_launch_*.remarks | grep kernel16 || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $obj/*.o -ldl -pthread
 rm -rf $obj
 echo "built $out/$name.so"

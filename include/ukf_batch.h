@@ -32,6 +32,13 @@
  *    synchronising call returns -- an engine that owns its stream may run a launch as two halves
  *    on two internal streams (ukfb_config.split_streams), so "the next call on the engine" is not
  *    a point after which an input buffer may be rewritten; ukfb_sync() is.
+ *  - filters are independent (the reference's are separate objects): no filter's result depends on another filter's
+ *    state or inputs.  Reproducibility: the same filter with the same inputs gives the same bits in any launch that
+ *    places it in a wavefront whose other three filters run the same number of mean iterations (always the case for the
+ *    same batch; also across batch sizes, shards and split launches in every workload of tests/ and bench.py);
+ *    otherwise the results agree to the remainder of the re-based rotation deltas, below 4e-14 -- the iteration count
+ *    is a wavefront's, a converged filter rides along unchanged.  Filters that commit nothing (uninitialised, gated
+ *    out, not factorisable) never influence their wave-mates.
  *  - per-filter failures never abort a call: they are reported in the per-filter status word
  *    (UKFB_ST_*), and a failing filter keeps the state it had before the call (the reference
  *    throws before mutating: UnscentedKalmanFilter.hpp:110-124).

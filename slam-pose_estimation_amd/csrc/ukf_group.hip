@@ -68,6 +68,9 @@ struct ukfb_group {
     std::vector<ncclComm_t> comms;
     std::vector<void*> send_pad, recv_pad;
     int64_t max_count = 0;
+    // event routing (ukfb_group_process_events): one pinned, grow-only buffer per shard
+    std::vector<void*> route_buf;
+    std::vector<size_t> route_cap;
 };
 
 namespace {
@@ -102,6 +105,13 @@ void release_gather(ukfb_group* g) {
     }
     g->send_pad.clear();
     g->recv_pad.clear();
+}
+
+void release_routing(ukfb_group* g) {
+    for (size_t r = 0; r < g->route_buf.size(); ++r)
+        if (g->route_buf[r]) (void)hipHostFree(g->route_buf[r]);
+    g->route_buf.clear();
+    g->route_cap.clear();
 }
 
 }  // namespace
@@ -152,6 +162,9 @@ int ukfb_group_destroy(ukfb_group* g) {
     if (!g) return UKFB_OK;
     release_gather(g);
     int rc = UKFB_OK;
+    // (the routing buffers feed asynchronous copies: every shard's stream drains in ukfb_destroy below before its memory
+    // goes, but the pinned buffers must outlive those copies -- ukfb_group_process_events returns only after they completed)
+    release_routing(g);
     for (ukfb_engine* e : g->engines) {
         const int r = ukfb_destroy(e);
         rc = rc ? rc : r;
@@ -380,44 +393,97 @@ int ukfb_group_process_events(ukfb_group* g, int64_t n_events, const int64_t* fi
     if (n_events == 0) return UKFB_OK;
     const size_t n = g->engines.size();
     struct Part {
-        std::vector<int64_t> f, t;
-        std::vector<int32_t> m;
-        std::vector<double> z, q;
         uint32_t st = 0;
         int64_t rounds = 0;
         int rc = UKFB_OK;
         std::string err;
     };
+    if (n > 255) return gfail(UKFB_ERR_INVALID_ARG, "ukfb_group_process_events: more than 255 shards");
     std::vector<Part> parts(n);
-    for (int64_t i = 0; i < n_events; ++i) {
-        const int64_t f = filter[i];
-        if (f < 0 || f >= g->total) return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_process_events: filter index outside the batch");
-        const size_t r = size_t(std::upper_bound(g->first.begin(), g->first.end(), f) - g->first.begin()) - 1;
-        Part& p = parts[r];
-        p.f.push_back(f - g->first[r]);
-        p.t.push_back(ts_us[i]);
-        p.m.push_back(meas_model[i]);
-        p.z.insert(p.z.end(), z + size_t(i) * 3, z + size_t(i) * 3 + 3);
-        p.q.insert(p.q.end(), Q + size_t(i) * 9, Q + size_t(i) * 9 + 9);
+    // pass 1 (this thread): the owner of every event and the shard sizes; pass 2 (the shard's thread): every shard collects
+    // its own events, in arrival order, into its pinned routing buffer and hands them to its engine
+    std::vector<uint8_t> owner(static_cast<size_t>(n_events));
+    std::vector<size_t> counts(n, 0);
+    {
+        const double per_filter = double(n) / double(g->total);   // (a multiply, not a 64-bit division per event)
+        for (int64_t i = 0; i < n_events; ++i) {
+            const int64_t f = filter[i];
+            if (f < 0 || f >= g->total) return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_process_events: filter index outside the batch");
+            size_t r = std::min(n - 1, size_t(double(f) * per_filter));   // shards differ by one filter at most: the guess is off by one at most
+            while (f < g->first[r]) --r;
+            while (f >= g->first[r] + g->count[r]) ++r;
+            owner[size_t(i)] = uint8_t(r);
+            ++counts[r];
+        }
     }
+    if (g->route_buf.empty()) {
+        g->route_buf.assign(n, nullptr);
+        g->route_cap.assign(n, 0);
+    }
+    constexpr size_t EVENT_BYTES = 2 * sizeof(int64_t) + sizeof(int32_t) + 12 * sizeof(double);
     const auto run = [&](size_t r) {
         Part& p = parts[r];
         ukfb_engine* e = g->engines[r];
-        if (p.f.empty()) {
+        const size_t m = counts[r];
+        ukfb::DeviceScope on_device(e->device);
+        if (on_device.err != hipSuccess) {
+            p.rc = UKFB_ERR_HIP;
+            p.err = "ukfb_group_process_events: hipSetDevice";
+            return;
+        }
+        if (m == 0) {
             // no sample for this shard: what the call does to a filter without samples -- a fresh, empty status word
-            ukfb::DeviceScope on_device(e->device);
-            if (on_device.err != hipSuccess ||
-                hipMemsetAsync(e->status, 0, size_t(e->cap) * sizeof(uint32_t), ukfb::main_stream(e)) != hipSuccess) {
+            if (hipMemsetAsync(e->status, 0, size_t(e->cap) * sizeof(uint32_t), ukfb::main_stream(e)) != hipSuccess) {
                 p.rc = UKFB_ERR_HIP;
                 p.err = "ukfb_group_process_events: status reset failed";
             }
             return;
         }
-        p.rc = ukfb_process_events(e, int64_t(p.f.size()), p.f.data(), p.t.data(), p.m.data(), p.z.data(), p.q.data(), &p.st, &p.rounds);
+        const int64_t f0 = g->first[r];
+        if (m == size_t(n_events)) {   // every event belongs to this shard: the caller's arrays as they are (indices shifted if need be)
+            std::vector<int64_t> shifted;
+            if (f0 != 0) {
+                shifted.resize(m);
+                for (size_t k = 0; k < m; ++k) shifted[k] = filter[k] - f0;
+            }
+            p.rc = ukfb_process_events(e, n_events, f0 ? shifted.data() : filter, ts_us, meas_model, z, Q, &p.st, &p.rounds);
+            if (p.rc) p.err = ukfb_last_error();
+            return;
+        }
+        const size_t need = m * EVENT_BYTES + 64;
+        if (g->route_cap[r] < need) {
+            if (g->route_buf[r]) (void)hipHostFree(g->route_buf[r]);
+            g->route_buf[r] = nullptr;
+            g->route_cap[r] = 0;
+            const size_t want = need + need / 4;
+            if (hipHostMalloc(&g->route_buf[r], want, hipHostMallocDefault) != hipSuccess) {
+                p.rc = UKFB_ERR_HIP;
+                p.err = "ukfb_group_process_events: pinned routing buffer";
+                return;
+            }
+            g->route_cap[r] = want;
+        }
+        // doubles first (8-byte aligned), then the 64-bit and 32-bit integers
+        double* pz = static_cast<double*>(g->route_buf[r]);
+        double* pq = pz + 3 * m;
+        int64_t* pf = reinterpret_cast<int64_t*>(pq + 9 * m);
+        int64_t* pt = pf + m;
+        int32_t* pm = reinterpret_cast<int32_t*>(pt + m);
+        size_t k = 0;
+        for (int64_t i = 0; i < n_events; ++i) {
+            if (owner[size_t(i)] != r) continue;
+            pf[k] = filter[i] - f0;
+            pt[k] = ts_us[i];
+            pm[k] = meas_model[i];
+            std::memcpy(pz + 3 * k, z + size_t(i) * 3, 3 * sizeof(double));
+            std::memcpy(pq + 9 * k, Q + size_t(i) * 9, 9 * sizeof(double));
+            ++k;
+        }
+        p.rc = ukfb_process_events(e, int64_t(m), pf, pt, pm, pz, pq, &p.st, &p.rounds);   // (returns after its copies completed)
         if (p.rc) p.err = ukfb_last_error();   // (the text is per thread)
     };
     size_t busy = 0;
-    for (const Part& p : parts) busy += p.f.empty() ? 0 : 1;
+    for (size_t r = 0; r < n; ++r) busy += counts[r] ? 1 : 0;
     if (busy <= 1) {
         for (size_t r = 0; r < n; ++r) run(r);
     } else {

@@ -28,6 +28,23 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     print("filters %d, events %d, rounds %d, status_or %d: %.1f ms -> %.1f M events/s" % (n, E, rounds, st, dt * 1e3, E / dt / 1e6))
 
+# the same host-resident stream over a sharded batch (ukfb_group_process_events: events routed to the owners on the host, one
+# thread per shard).  On a one-GPU box every shard sits on device 0 -- the figure shows the cost of the routing, not a speed-up.
+shards = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+if shards > 0:
+    g = spe.UKFGroup(spe.MODEL_POSE, spe.F64, n, [0] * shards)
+    for rep in range(3):
+        g.initialize(mu, cov)
+        for sh in g.shards:
+            sh["engine"].set_last_measurement_time(np.full(sh["count"], 1_000_000, dtype=np.int64))
+        g.sync()
+        t0 = time.perf_counter()
+        st, rounds = g.process_events(f, t, m, z, Q)
+        g.sync()
+        dt = time.perf_counter() - t0
+        print("group of %d shards on device 0: events %d, rounds %d, status_or %d: %.1f ms -> %.1f M events/s" % (shards, E, rounds, st, dt * 1e3, E / dt / 1e6))
+    g.close()
+
 # the same stream resident in HBM (engine precision): ordering, ranking and scatter on the device
 td = torch.float64
 d = [torch.from_numpy(f).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(m).cuda(),

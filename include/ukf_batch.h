@@ -336,7 +336,9 @@ int ukfb_group_set_process_noise(ukfb_group* g, const double* R);
 int ukfb_group_pose_set_acceleration(ukfb_group* g, int64_t first, int64_t count, const double* acc_mu, const double* acc_cov);
 int ukfb_group_orient_set_params(ukfb_group* g, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3]);
 int ukfb_group_orient_set_inputs(ukfb_group* g, int64_t first, int64_t count, const double* gyro, const double* acc);
-/* hot path from host arrays over the whole batch (z [total][3], Q [total][3][3]) */
+/* hot path from host arrays over the whole batch (z [total][3], Q [total][3][3]).  From 32 768 filters on, the host-array calls
+ * of a group (these, ukfb_group_initialize, ukfb_group_get_state, ukfb_group_cycle_timestamps) run one host thread per shard for
+ * the duration of the call, so that the uploads of all devices proceed at once over their own PCIe links. */
 int ukfb_group_predict(ukfb_group* g, double dt);
 int ukfb_group_update(ukfb_group* g, int meas_model, const double* z, const double* Q);
 int ukfb_group_cycle(ukfb_group* g, double dt, int meas_model, const double* z, const double* Q);

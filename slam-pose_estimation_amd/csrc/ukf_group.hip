@@ -107,6 +107,37 @@ void release_gather(ukfb_group* g) {
     g->recv_pad.clear();
 }
 
+// Host-array calls over a large batch: every shard's call stages and uploads its range, which occupies the calling thread
+// for the duration of the copy -- one thread per shard keeps the PCIe links of all devices busy at once.  Small batches and
+// the device-pointer calls (which only enqueue) stay on the calling thread: a thread costs more than they do.
+constexpr int64_t THREAD_MIN_FILTERS = 32768;
+template <class F> int fan_out(ukfb_group* g, int64_t filters_touched, F&& call) {   // call(shard) -> rc, text in ukfb_last_error()
+    const size_t n = g->engines.size();
+    if (n == 1 || filters_touched < THREAD_MIN_FILTERS) {
+        for (size_t r = 0; r < n; ++r) {
+            const int rc = call(r);
+            if (rc) return rc;
+        }
+        return UKFB_OK;
+    }
+    std::vector<int> rcs(n, UKFB_OK);
+    std::vector<std::string> errs(n);
+    const auto run = [&](size_t r) {
+        rcs[r] = call(r);
+        if (rcs[r]) errs[r] = ukfb_last_error();   // (the text is per thread)
+    };
+    std::vector<std::thread> workers;
+    for (size_t r = 1; r < n; ++r) workers.emplace_back(run, r);
+    run(0);
+    for (std::thread& w : workers) w.join();
+    for (size_t r = 0; r < n; ++r)
+        if (rcs[r]) {
+            ukfb::set_error_text(errs[r]);
+            return rcs[r];
+        }
+    return UKFB_OK;
+}
+
 void release_routing(ukfb_group* g) {
     for (size_t r = 0; r < g->route_buf.size(); ++r)
         if (g->route_buf[r]) (void)hipHostFree(g->route_buf[r]);
@@ -197,27 +228,22 @@ int ukfb_group_initialize(ukfb_group* g, int64_t first, int64_t count, const dou
     if (!g || !mu || !cov || first < 0 || count < 0 || first + count > g->total)
         return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_initialize: bad range");
     const size_t DD = size_t(g->D) * g->D;
-    for (size_t r = 0; r < g->engines.size(); ++r) {
+    return fan_out(g, count, [&](size_t r) {
         const Cut c = cut(g, int(r), first, count);
-        if (!c.len) continue;
-        const int rc = ukfb_initialize(g->engines[r], c.dst, c.len, mu + size_t(c.src) * g->S, cov + size_t(c.src) * DD);
-        if (rc) return efail(rc);
-    }
-    return UKFB_OK;
+        return c.len ? ukfb_initialize(g->engines[r], c.dst, c.len, mu + size_t(c.src) * g->S, cov + size_t(c.src) * DD) : int(UKFB_OK);
+    });
 }
 
 int ukfb_group_get_state(ukfb_group* g, int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised) {
     if (!g || first < 0 || count < 0 || first + count > g->total)
         return gfail(UKFB_ERR_OUT_OF_RANGE, "ukfb_group_get_state: bad range");
     const size_t DD = size_t(g->D) * g->D;
-    for (size_t r = 0; r < g->engines.size(); ++r) {
+    return fan_out(g, count, [&](size_t r) {
         const Cut c = cut(g, int(r), first, count);
-        if (!c.len) continue;
-        const int rc = ukfb_get_state(g->engines[r], c.dst, c.len, mu ? mu + size_t(c.src) * g->S : nullptr,
-                                      cov ? cov + size_t(c.src) * DD : nullptr, initialised ? initialised + c.src : nullptr);
-        if (rc) return efail(rc);
-    }
-    return UKFB_OK;
+        return c.len ? ukfb_get_state(g->engines[r], c.dst, c.len, mu ? mu + size_t(c.src) * g->S : nullptr,
+                                      cov ? cov + size_t(c.src) * DD : nullptr, initialised ? initialised + c.src : nullptr)
+                     : int(UKFB_OK);
+    });
 }
 
 int ukfb_group_get_status(ukfb_group* g, int64_t first, int64_t count, uint32_t* status) {
@@ -333,11 +359,9 @@ int ukfb_group_orient_bind_inputs_dev(ukfb_group* g, const void* const* gyro_dev
 // host arrays over the whole batch (z [total][3], Q [total][3][3]): every shard uploads and launches its range
 int ukfb_group_cycle(ukfb_group* g, double dt, int meas_model, const double* z, const double* Q) {
     if (!g || !z || !Q) return UKFB_ERR_INVALID_ARG;
-    for (size_t r = 0; r < g->engines.size(); ++r) {
-        const int rc = ukfb_cycle(g->engines[r], dt, meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9);
-        if (rc) return efail(rc);
-    }
-    return UKFB_OK;
+    return fan_out(g, g->total, [&](size_t r) {
+        return ukfb_cycle(g->engines[r], dt, meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9);
+    });
 }
 
 int ukfb_group_predict(ukfb_group* g, double dt) {
@@ -351,11 +375,9 @@ int ukfb_group_predict(ukfb_group* g, double dt) {
 
 int ukfb_group_update(ukfb_group* g, int meas_model, const double* z, const double* Q) {
     if (!g || !z || !Q) return UKFB_ERR_INVALID_ARG;
-    for (size_t r = 0; r < g->engines.size(); ++r) {
-        const int rc = ukfb_update(g->engines[r], meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9, nullptr);
-        if (rc) return efail(rc);
-    }
-    return UKFB_OK;
+    return fan_out(g, g->total, [&](size_t r) {
+        return ukfb_update(g->engines[r], meas_model, z + size_t(g->first[r]) * 3, Q + size_t(g->first[r]) * 9, nullptr);
+    });
 }
 
 // per-filter model ids on the devices (the mixed asynchronous stream of BASELINE config 5, one pointer per shard)
@@ -372,12 +394,10 @@ int ukfb_group_cycle_mixed_dev(ukfb_group* g, double dt, const int32_t* const* m
 // fused predictionStepFromSampleTime + integrateMeasurement per filter, host arrays over the whole batch
 int ukfb_group_cycle_timestamps(ukfb_group* g, const int64_t* ts_us, const int32_t* meas_model, const double* z, const double* Q) {
     if (!g || !ts_us || !meas_model) return UKFB_ERR_INVALID_ARG;
-    for (size_t r = 0; r < g->engines.size(); ++r) {
+    return fan_out(g, g->total, [&](size_t r) {
         const size_t o = size_t(g->first[r]);
-        const int rc = ukfb_cycle_timestamps(g->engines[r], ts_us + o, meas_model + o, z ? z + o * 3 : nullptr, Q ? Q + o * 9 : nullptr);
-        if (rc) return efail(rc);
-    }
-    return UKFB_OK;
+        return ukfb_cycle_timestamps(g->engines[r], ts_us + o, meas_model + o, z ? z + o * 3 : nullptr, Q ? Q + o * 9 : nullptr);
+    });
 }
 
 // The time-ordered asynchronous stream over a sharded batch: events are routed to the shard that owns their filter (a

@@ -178,3 +178,32 @@ def test_group_event_stream_timestamps_and_per_filter_models(spe, prec):
     m1, c1, _ = one.state(); mg, cg, _ = grp.state()
     assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and (one.status() == grp.status()).all()
     grp.close(); one.close()
+
+
+def test_host_array_calls_of_a_large_group_fan_out_on_threads(spe):
+    """From 32 768 filters on, the host-array calls of a group (initialize, get_state, cycle, update, cycle_timestamps) run
+    one host thread per shard, so that every device's upload proceeds at once.  Same results as ONE engine, bit for bit."""
+    s = spe.synth
+    rng = np.random.default_rng(23)
+    n = 40_001
+    mu, cov = s.pose_initial(n)
+    acc, z, Q = s.pose_cycle_inputs(n, 0, mu[:, :3], random_q=True)
+    one = spe.BatchPoseUKF(n)
+    grp = spe.UKFGroup(spe.MODEL_POSE, spe.F64, n, [0, 0, 0])
+    one.initialize(mu, cov); grp.initialize(mu, cov)
+    one.set_acceleration(acc, 0.01 * np.eye(3)); grp.set_acceleration(acc, 0.01 * np.eye(3))
+    for k in range(3):
+        one.cycle(0.01, spe.MEAS_POS3, z, Q); grp.cycle(0.01, spe.MEAS_POS3, z, Q)
+    one.update(spe.MEAS_VEL3, mu[:, 7:10], Q); grp.update(spe.MEAS_VEL3, mu[:, 7:10], Q)
+    ts = np.where(rng.random(n) < 0.7, 3_000_000 + rng.integers(0, 20_000, size=n), -1).astype(np.int64)
+    mod = rng.choice(np.array([-1, 0, 4], dtype=np.int32), size=n)
+    zt = s.pose_measurement_for_model(mu, np.maximum(mod, 0), 0.05 * rng.normal(size=(n, 3)))
+    one.cycle_timestamps(ts, mod, zt, Q); grp.cycle_timestamps(ts, mod, zt, Q)
+    m1, c1, i1 = one.state(); mg, cg, ig = grp.state()
+    assert np.array_equal(m1, mg) and np.array_equal(c1, cg) and i1.all() and ig.all() and (one.status() == grp.status()).all()
+    assert max_abs(m1, mu) > 1e-3 and np.isfinite(m1).all()
+    # an error inside one shard's thread comes back through the group call with its text
+    with pytest.raises(spe.UkfbError) as ei:
+        grp.update(99, z, Q)
+    assert "measurement model" in str(ei.value)
+    grp.close(); one.close()

@@ -40,3 +40,19 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): zd.copy_(zp, non_blocking=True); Qd.copy_(Qp, non_blocking=True)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print(f"pinned H2D of z + Q alone ({(z.nbytes + Q.nbytes) / 1e6:.0f} MB): {dt * 1e3:.2f} ms = {(z.nbytes + Q.nbytes) / dt / 1e9:.1f} GB/s")
+# the same host arrays through a device group (ukfb_group_cycle: every shard uploads and launches its range).  On a one-GPU
+# box the shards share device 0 and its PCIe link: the figure shows what the fan-out costs, not what several links give.
+shards = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if shards > 0:
+    e.close()
+    g = spe.UKFGroup(spe.MODEL_POSE, prec, n, [0] * shards)
+    for lo in range(0, n, CH):
+        hi = min(n, lo + CH)
+        mu, cov = spe.synth.pose_initial(hi - lo, first=lo); g.initialize(mu, cov, first=lo)
+    g.set_acceleration(acc, 0.01 * np.eye(3))
+    g.cycle(0.01, spe.MEAS_POS3, z, Q); g.sync()
+    t0 = time.perf_counter(); k = 5
+    for _ in range(k): g.cycle(0.01, spe.MEAS_POS3, z, Q)
+    g.sync(); dt = (time.perf_counter() - t0) / k
+    print(f"group of {shards} shards on device 0, host pointers (ukfb_group_cycle): {dt * 1e3:.2f} ms per cycle -> {n / dt / 1e6:.1f} M filter-cycles/s")
+    g.close()

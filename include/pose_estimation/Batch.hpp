@@ -122,22 +122,14 @@ public:
     void getRotationRates(int64_t first, int64_t count, double* out) { check(ukfb_orient_get_rotation_rate(engine, first, count, out)); }
 };
 
-/** One host process, several MI355X: `total` independent PoseUKF filters in contiguous shards, one engine per device
+/** One host process, several MI355X: `total` independent filters in contiguous shards, one engine per device
  *  (ukfb_group_* of ukf_batch.h).  Filters never read each other (UnscentedKalmanFilter.hpp:150), so the shards need no
  *  collective on the data path; gatherMeans is the one exchange (RCCL all-gather over xGMI).  Whole-batch host arrays are
  *  in batch numbering; device-pointer arguments are one pointer PER SHARD (memory on that shard's device). */
-class ShardedBatchPoseUKF
+class ShardedBatchUKF
 {
 public:
-    ShardedBatchPoseUKF(int64_t total, const std::vector<int>& devices, int precision = UKFB_F64) : group(NULL), n(total)
-    {
-        if (ukfb_group_create(&group, UKFB_MODEL_POSE, precision, total, devices.data(), static_cast<int>(devices.size())) != UKFB_OK)
-            throw std::runtime_error(std::string("pose_estimation: MI355X engine group unavailable: ") + ukfb_last_error());
-        double R[144] = {0};   // PoseUKF.cpp:103-107
-        for (int k = 0; k < 3; ++k) { R[k * 13] = 0.01; R[(3 + k) * 13] = 0.001; R[(6 + k) * 13] = 0.00001; R[(9 + k) * 13] = 0.00001; }
-        check(ukfb_group_set_process_noise(group, R));
-    }
-    ~ShardedBatchPoseUKF() { ukfb_group_destroy(group); }
+    virtual ~ShardedBatchUKF() { ukfb_group_destroy(group); }
 
     int64_t capacity() const { return n; }
     int shards() const { return ukfb_group_size(group); }
@@ -149,10 +141,9 @@ public:
         check(ukfb_group_shard(group, r, &e, device, first, count));
         return e;
     }
-    void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov) { check(ukfb_group_initialize(group, first, count, mu, cov)); }
+    virtual void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov) { check(ukfb_group_initialize(group, first, count, mu, cov)); }
     void getCurrentStates(int64_t first, int64_t count, double* mu, double* cov, uint8_t* initialised = NULL) { check(ukfb_group_get_state(group, first, count, mu, cov, initialised)); }
     void setProcessNoiseCovariance(const double* R) { check(ukfb_group_set_process_noise(group, R)); }
-    void setAccelerations(int64_t first, int64_t count, const double* acc_mu, const double* acc_cov3x3) { check(ukfb_group_pose_set_acceleration(group, first, count, acc_mu, acc_cov3x3)); }
     void predictionStep(double delta_t) { check(ukfb_group_predict(group, delta_t)); }
     void integrateMeasurements(int model, const double* z, const double* Q) { check(ukfb_group_update(group, model, z, Q)); }
     void cycle(double delta_t, int model, const double* z, const double* Q) { check(ukfb_group_cycle(group, delta_t, model, z, Q)); }
@@ -172,18 +163,58 @@ public:
         check(ukfb_group_process_events(group, n_events, filter, ts_us, model, z, Q, NULL, &rounds));
         return rounds;
     }
-    void bindAccelerationsDev(const void* const* acc_mu_dev) { check(ukfb_group_pose_bind_acceleration_dev(group, acc_mu_dev)); }
-    /** RCCL all-gather: out_dev[r] ([total][13], engine precision, on shard r's device) receives every filter's mean */
+    /** RCCL all-gather: out_dev[r] ([total][S], engine precision, on shard r's device) receives every filter's mean */
     void gatherMeans(void* const* out_dev) { check(ukfb_group_gather_means(group, out_dev)); }
     uint32_t statusSummary() { uint32_t v = 0; check(ukfb_group_get_status_summary(group, &v)); return v; }
     void sync() { check(ukfb_group_sync(group)); }
 
-private:
+protected:
+    ShardedBatchUKF(int model, int64_t total, const std::vector<int>& devices, int precision) : group(NULL), n(total)
+    {
+        if (ukfb_group_create(&group, model, precision, total, devices.data(), static_cast<int>(devices.size())) != UKFB_OK)
+            throw std::runtime_error(std::string("pose_estimation: MI355X engine group unavailable: ") + ukfb_last_error());
+    }
     void check(int rc) const { if (rc != UKFB_OK) throw std::runtime_error(std::string("pose_estimation engine group: ") + ukfb_last_error()); }
     ukfb_group* group;
     int64_t n;
-    ShardedBatchPoseUKF(const ShardedBatchPoseUKF&);
-    ShardedBatchPoseUKF& operator=(const ShardedBatchPoseUKF&);
+
+private:
+    ShardedBatchUKF(const ShardedBatchUKF&);
+    ShardedBatchUKF& operator=(const ShardedBatchUKF&);
+};
+
+class ShardedBatchPoseUKF : public ShardedBatchUKF
+{
+public:
+    ShardedBatchPoseUKF(int64_t total, const std::vector<int>& devices, int precision = UKFB_F64) : ShardedBatchUKF(UKFB_MODEL_POSE, total, devices, precision)
+    {
+        double R[144] = {0};   // PoseUKF.cpp:103-107
+        for (int k = 0; k < 3; ++k) { R[k * 13] = 0.01; R[(3 + k) * 13] = 0.001; R[(6 + k) * 13] = 0.00001; R[(9 + k) * 13] = 0.00001; }
+        setProcessNoiseCovariance(R);
+    }
+    void setAccelerations(int64_t first, int64_t count, const double* acc_mu, const double* acc_cov3x3) { check(ukfb_group_pose_set_acceleration(group, first, count, acc_mu, acc_cov3x3)); }
+    void bindAccelerationsDev(const void* const* acc_mu_dev) { check(ukfb_group_pose_bind_acceleration_dev(group, acc_mu_dev)); }
+};
+
+class ShardedBatchOrientationUKF : public ShardedBatchUKF
+{
+public:
+    ShardedBatchOrientationUKF(int64_t total, const std::vector<int>& devices, double gyro_bias_tau, double acc_bias_tau, const double earth_rotation[3],
+                               int precision = UKFB_F64)
+        : ShardedBatchUKF(UKFB_MODEL_ORIENT, total, devices, precision)
+    {
+        check(ukfb_group_orient_set_params(group, gyro_bias_tau, acc_bias_tau, earth_rotation));
+    }
+    /** initializeFilter plus the reference constructor's input latches (OrientationUKF.cpp:49-50), as BatchOrientationUKF */
+    virtual void initializeFilters(int64_t first, int64_t count, const double* mu, const double* cov)
+    {
+        ShardedBatchUKF::initializeFilters(first, count, mu, cov);
+        std::vector<double> gyro(static_cast<size_t>(count) * 3, 0.0), acc(static_cast<size_t>(count) * 3, 0.0);
+        for (int64_t i = 0; i < count; ++i) acc[static_cast<size_t>(i) * 3 + 2] = mu[static_cast<size_t>(i) * 14 + 13];
+        setInputs(first, count, gyro.data(), acc.data());
+    }
+    void setInputs(int64_t first, int64_t count, const double* gyro, const double* acc) { check(ukfb_group_orient_set_inputs(group, first, count, gyro, acc)); }
+    void bindInputsDev(const void* const* gyro_dev, const void* const* acc_dev) { check(ukfb_group_orient_bind_inputs_dev(group, gyro_dev, acc_dev)); }
 };
 
 }

@@ -147,6 +147,28 @@ int main()
         for (int k = 0; k < NB * 14; ++k) same = same && ma[k] == mb[k];
         for (int k = 0; k < NB * 169; ++k) same = same && ca[k] == cb[k];
         std::printf("\"batch_cycles_bit_equal\": %s,\n", same ? "true" : "false");
+        // ShardedBatchOrientationUKF: the same three cycles on two shards (2 + 1 filters) of device 0, latches included
+        std::vector<int> devs(2, 0);
+        ShardedBatchOrientationUKF sharded(NB, devs, 3600.0, 1800.0, earth);
+        sharded.setProcessNoiseCovariance(Rn.data());
+        sharded.initializeFilters(0, NB, mi, ci);
+        sharded.predictionStep(0.02);                 // (before any IMU sample: the constructor's latches)
+        BatchOrientationUKF ref(NB, 3600.0, 1800.0, earth);
+        ref.setProcessNoiseCovariance(Rn.data());
+        ref.initializeFilters(0, NB, mi, ci);
+        ref.predictionStep(0.02);
+        for (int c = 0; c < C; ++c) {
+            sharded.setInputs(0, NB, gyro + c * NB * 3, accs + c * NB * 3);
+            sharded.cycle(0.01, UKFB_MEAS_ORIENT_BODYVEL3, zz + c * NB * 3, QQ + c * NB * 9);
+            ref.setInputs(0, NB, gyro + c * NB * 3, accs + c * NB * 3);
+            ref.cycle(0.01, UKFB_MEAS_ORIENT_BODYVEL3, zz + c * NB * 3, QQ + c * NB * 9);
+        }
+        sharded.sync();
+        ref.getCurrentStates(0, NB, ma, ca); sharded.getCurrentStates(0, NB, mb, cb);
+        same = sharded.shards() == 2;
+        for (int k = 0; k < NB * 14; ++k) same = same && ma[k] == mb[k] && std::isfinite(mb[k]);
+        for (int k = 0; k < NB * 169; ++k) same = same && ca[k] == cb[k];
+        std::printf("\"sharded_orient_bit_equal\": %s,\n", same ? "true" : "false");
     }
 
     // ---------------- ShardedBatchPoseUKF (ukfb_group_*): two shards -- here both on device 0, on a node one per GPU --

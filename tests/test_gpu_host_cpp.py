@@ -33,6 +33,7 @@ def test_host_cpp_classes_match_the_oracle(oracle, onp):
     assert r["batch_orient_vs_scalar"] <= 1e-12 and abs(r["batch_orient_dvz"]) < 1e-3
     assert r["batch_cycles_bit_equal"] is True      # BatchUKF::cycles (one launch) == the same samples one cycle() at a time
     # ShardedBatchPoseUKF (ukfb_group_*: one engine per shard) == one BatchPoseUKF over the same filters, bit for bit
+    assert r["sharded_orient_bit_equal"] is True
     assert r["sharded_bit_equal"] is True and r["sharded_moved"] > 1e-4 and r["sharded_shard1"] == [0, 4, 3]
     # ---- PoseUKF sequence restated with the oracle
     mu = np.array([[1.0, -2.0, 0.5, 0.0, 0.3826834323650898, 0.0, 0.9238795325112867, 0.3, 0.1, -0.2, 0.05, -0.02, 0.1]])

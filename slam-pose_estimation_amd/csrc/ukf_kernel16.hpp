@@ -234,6 +234,9 @@ template <class T> struct MT<OrientM<T>> {
 #ifndef UKFB_ORIENT64_TRIM
 #define UKFB_ORIENT64_TRIM 1   // 0: the OrientationState fp64 slice of round 2 (14 656 B, 10 workgroups per CU)
 #endif
+#ifndef UKFB_PREFETCH_ORIENT64
+#define UKFB_PREFETCH_ORIENT64 1   // 0: the OrientationState fp64 multi-cycle kernel loads every cycle's inputs itself (as the fp32 kernels do)
+#endif
 #ifndef UKFB_F32_TRIM
 #define UKFB_F32_TRIM 1   // 0: the fp32 Pose slice as before round 2's last trim (424 floats, 21 workgroups per CU): -2.7 %
 #endif
@@ -686,6 +689,7 @@ template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W6
 template <class T, class M, bool MULTI> constexpr int waves16() {
     if (sizeof(T) == 4) return MULTI ? 4 : min_waves16<T>();
     if (Layout16<T, M>::COMPACT && UKFB_LATE_XM != 0) return MULTI ? 3 : 4;
+    if (M::MODEL != 0 && MULTI) return 3;   // OrientationState fp64, multi-cycle: three wavefronts per SIMD (192 VGPRs = two before round 3's loop hygiene)
     return min_waves16<T>();
 }
 
@@ -739,6 +743,13 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 #define UKFB_HEADLINE_ACC(x) (x)
 #endif
     if constexpr (!INDIRECT) __builtin_assume(a.fidx == nullptr);
+    // Optional per-filter streams.  A multi-cycle launch has none of them BY TYPE (a compile-time null, not an assumption about
+    // a kernel argument: the loads of an argument inside the cycle loop are not the load the assumption was made about, and
+    // the timestamp path stayed alive in the multi-cycle kernels -- registers around the whole loop, and a wavefront per SIMD
+    // in the OrientationState fp64 kernel).
+    const int64_t* const a_ts = MULTI ? nullptr : a.ts;
+    const double* const a_dt = MULTI ? nullptr : a.dt;
+    const uint8_t* const a_active = MULTI ? nullptr : a.active;
     if constexpr (MULTI) {
         // multi-cycle launches are direct launches with one dt per cycle for every filter (checked by the host): no
         // per-filter timestamps, time steps, activity flags or filter index list to keep alive
@@ -789,10 +800,10 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     int64_t* const last_ts_p = at_wg(a.last_ts, 1);
     const T* const in_a_p = at_wg(a.in_a, 3);
     const T* const in_b_p = at_wg(a.in_b, 3);
-    const int64_t* const ts_p = at_wg(a.ts, 1);
-    const double* const dt_p = at_wg(a.dt, 1);
+    const int64_t* const ts_p = at_wg(a_ts, 1);
+    const double* const dt_p = at_wg(a_dt, 1);
     const int32_t* const meas_p = at_wg(a.meas, 1);
-    const uint8_t* const active_p = at_wg(a.active, 1);
+    const uint8_t* const active_p = at_wg(a_active, 1);
     const T* const z_p = at_wg(a.z, 3);
     const IDX q_stride = (!MULTI && a.q_uniform) ? 0 : 9;     // batch-uniform measurement covariance: every filter reads the same 9 scalars
     const T* const Q_p = at_wg(a.Q, int64_t(q_stride));
@@ -875,8 +886,13 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     };
     T zq_l = T(0);
     int slot = MULTI ? a.cyc_first : 0;
+    // fp64 (3 wavefronts per SIMD, latency-bound): a multi-cycle launch requests the inputs of the next cycle before this
+    // cycle's arithmetic, into registers -- the first cycle's here, with the state (OrientationState fp64, same-box: 805 M
+    // filter-cycles/s with the prefetch, 787 M without; UKFB_PREFETCH_ORIENT64).  The fp32 multi-cycle kernels (6 per SIMD,
+    // issue-bound) load every cycle's inputs at the head of that cycle: nothing is carried around the cycle loop.
+    constexpr bool PREFETCH = MULTI && sizeof(T) == 8 && (UKFB_PREFETCH_ORIENT64 != 0 || M::MODEL == 0);
     if constexpr (MULTI) {
-        load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
+        if constexpr (PREFETCH) load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
     } else {
         if constexpr (DO_PREDICT) {
             const T* pa = at(in_a_p, fc * 3);
@@ -944,9 +960,6 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         asm volatile("" : "+s"(dt_uniform_c));
         asm volatile("" : "+s"(meas_uniform_c));
     }
-    // fp64 (3 wavefronts per SIMD, latency-bound): the inputs of the next cycle are requested before this cycle's
-    // arithmetic, into registers.  fp32 (6 per SIMD, issue-bound, 3 registers from its budget): every cycle loads its own.
-    constexpr bool PREFETCH = MULTI && sizeof(T) == 8;
     T nx_a[3] = {T(0), T(0), T(0)}, nx_w[3] = {T(0), T(0), T(0)}, nx_zq = T(0);
     int32_t nx_mid = 0;
     if constexpr (MULTI) {
@@ -954,8 +967,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             const int nslot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
             slot = (cyc + 1 < ncyc) ? nslot : slot;
             load_inputs(slot, nx_a, nx_w, nx_zq, nx_mid);
-        } else if (cyc > 0) {
-            slot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
+        } else {
+            const int nslot = (slot + 1 >= a.cyc_ring) ? 0 : (slot + 1);
+            slot = (cyc > 0) ? nslot : slot;
             load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
         }
     }
@@ -970,11 +984,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     bool noev = false;   // ts < 0: this filter has no sample in this call -> neither predicted nor updated
     T dtT = T(0);
     if constexpr (DO_PREDICT) {
-        const bool use_ts = a.ts != nullptr;
+        const bool use_ts = a_ts != nullptr;
         noev = use_ts && (ts_l < 0);
         const bool first = use_ts && (last_l == 0) && !noev;
         double dt;
-        if (!use_ts && !a.dt) {
+        if (!use_ts && !a_dt) {
             // one dt for the whole launch (kernel argument): the gate is scalar arithmetic, one select per lane
             dt = dt_uniform_c;
             const bool neg = dt < 0.0, small = dt <= a.min_dt, large = dt > a.max_dt;
@@ -983,7 +997,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             p_error = live && (neg || (!small && large));
             do_p = live && code == 0u;
         } else {
-            dt = a.dt ? dt_l : dt_uniform_c;
+            dt = a_dt ? dt_l : dt_uniform_c;
             if (use_ts)   // the IEEE division of base::Time::toSeconds only where it is needed
                 dt = (first || noev) ? 0.0 : double(ts_l - last_l) / 1000000.0;
             ts_store = use_ts && live && l == 0 && !noev && (first || dt > a.min_dt);
@@ -1010,7 +1024,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     int mid = -1;
     if constexpr (DO_UPDATE) {
         mid = a.meas ? mid_l : meas_uniform_c;
-        const bool act = M::meas_valid(mid) && (a.active ? act_b != 0 : true);
+        const bool act = M::meas_valid(mid) && (a_active ? act_b != 0 : true);
         do_u = live && act && !p_error && !noev;
         // (a scheduled prediction-only cycle of a multi-cycle launch is a plain predictionStep: no INACTIVE mark)
         const bool predict_only = MULTI && a.cyc_sched != 0 && meas_uniform_c < 0;
@@ -1631,6 +1645,17 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             // Measurement statistics: S (innovation covariance), cx (row l of Sigma_xz), innovation.
             bool ok1 = true, zconv = true;
             T Sm[9], cx[3], innov[3];
+            if constexpr (MULTI && sizeof(T) == 8 && M::MODEL != 0) {
+                // Inside the cycle loop a variable that is only assigned under a wave-uniform branch carries its (unused) value of
+                // the previous cycle around the loop: a register pair each, for the whole cycle.  Fifteen fp64 values here --
+                // with them the OrientationState fp64 multi-cycle kernel needed 192 VGPRs (two wavefronts per SIMD, slower than
+                // single launches), without them 155 (three; +15 %, same-box A/B).  The other multi-cycle kernels have the
+                // registers to spare and skip the fifteen moves per cycle (-0.5 ... -1.3 % with them).
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Sm[k] = T(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cx[k] = innov[k] = T(0);
+            }
             const int la = has_pair ? l : (D - 1);
             if (MT<M>::HAS_EUCLID_MEAS) {
                 // Sub-state selections (PoseUKF.cpp:7-26,35-69) are LINEAR in the tangent, and the unscented

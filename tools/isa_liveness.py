@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Approximate VGPR liveness per phase of the tuned kernel from its assembly (no GPU needed).
+"""VGPR liveness per phase of the tuned kernel from its assembly (no GPU needed).
 
-Backward scan over the kernel's instructions in layout order, treating the code as straight-line (loops and the few
-wave-uniform branches make this an approximation: a value defined before a loop and used inside it is live throughout,
-which a single backward pass over the layout order sees as long as the use follows the definition in the text).  Prints the
-maximum number of simultaneously live VGPRs inside each phase (UKFB_PHASE_MARKS) -- where the register budget is spent.
+Builds the control-flow graph of the kernel's instructions (labels, s_branch / s_cbranch_*), runs the backward liveness
+dataflow to its fixpoint and prints the maximum number of simultaneously live VGPRs inside each phase (UKFB_PHASE_MARKS) --
+where the register budget is spent -- and, for a multi-cycle kernel, what is live at the head of the cycle loop.  Exec-masked
+writes are treated as full definitions (an under-estimate where a divergent region writes part of a register).
 
 usage: tools/isa_liveness.py [pose|orient] [f64|f32] [cycle|predict|update|multi] [extra hipcc flags...]"""
 import os
@@ -43,6 +43,7 @@ def main():
     start = next(i for i, l in enumerate(text) if l.startswith("_ZN4ukfb12ukf_kernel16") and flags in l and ":" in l)
     ins = []   # (phase, defs, uses)
     cur = "entry"
+    labels, back_edges, pending = {}, [], []   # label -> index of the next instruction; (branch index, target index) of backward branches; all branches
     for line in text[start + 1:]:
         s = line.strip()
         if s.startswith(".Lfunc_end"):
@@ -51,6 +52,9 @@ def main():
         if m:
             cur = m.group(1)
             continue
+        if s.startswith(".LBB") and s.split(";")[0].strip().endswith(":"):
+            labels[s.split(":")[0]] = len(ins)
+            continue
         if not s or s.startswith((";", ".", "_Z")) or s.endswith(":"):
             continue
         s = s.split(";")[0]
@@ -58,6 +62,12 @@ def main():
         ops = [o.strip() for o in rest.split(",")]
         if not ops or not ops[0]:
             continue
+        if op.startswith(("s_cbranch", "s_branch")):
+            pending.append((len(ins), ops[0], op.startswith("s_branch")))
+            if ops[0] in labels:
+                back_edges.append((len(ins), labels[ops[0]]))
+        if op == "s_endpgm":
+            pending.append((len(ins), None, True))
         stores = op.startswith(("ds_write", "ds_store", "global_store", "scratch_store", "buffer_store", "flat_store")) or \
             op.startswith(("v_cmp", "s_")) and not op.startswith("v_cmpx")
         if stores:
@@ -68,12 +78,59 @@ def main():
             if op.startswith(("v_fmac", "v_mac", "v_pk_fmac")) or "dpp" in op or op.startswith("v_cndmask"):
                 u |= d          # destructive forms read their destination (a DPP move keeps lanes it does not write)
         ins.append((cur, d, u))
-    live = set()
+    branch_at = {idx: ((labels.get(lbl) if lbl is not None else None), uncond) for idx, lbl, uncond in pending}
+    # proper liveness over the control-flow graph: basic blocks end at branches and begin at labels; a conditional branch
+    # falls through and jumps, s_branch only jumps; backward dataflow to the fixpoint, then the per-instruction live sets
+    n = len(ins)
+    leaders = {0} | set(labels.values()) | {b + 1 for b in branch_at}
+    leaders = sorted(x for x in leaders if x < n)
+    block_of = {}
+    blocks = []
+    for bi, st in enumerate(leaders):
+        en = leaders[bi + 1] if bi + 1 < len(leaders) else n
+        blocks.append((st, en))
+        for k in range(st, en):
+            block_of[k] = bi
+    succ = [[] for _ in blocks]
+    for bi, (st, en) in enumerate(blocks):
+        last = en - 1
+        if last in branch_at:
+            tgt, uncond = branch_at[last]
+            if tgt is not None and tgt < n:
+                succ[bi].append(block_of[tgt])
+            if not uncond and en < n:
+                succ[bi].append(block_of[en])
+        elif en < n:
+            succ[bi].append(block_of[en])
+    live_in = [set() for _ in blocks]
+    changed = True
+    while changed:
+        changed = False
+        for bi in range(len(blocks) - 1, -1, -1):
+            st, en = blocks[bi]
+            live = set()
+            for sb in succ[bi]:
+                live |= live_in[sb]
+            for k in range(en - 1, st - 1, -1):
+                live = (live - ins[k][1]) | ins[k][2]
+            if live != live_in[bi]:
+                live_in[bi] = live
+                changed = True
     peak = {}
-    for ph, d, u in reversed(ins):
-        live -= d
-        live |= u
-        peak[ph] = max(peak.get(ph, 0), len(live))
+    where = {}
+    for bi, (st, en) in enumerate(blocks):
+        live = set()
+        for sb in succ[bi]:
+            live |= live_in[sb]
+        for k in range(en - 1, st - 1, -1):
+            live = (live - ins[k][1]) | ins[k][2]
+            ph = ins[k][0]
+            if len(live) > peak.get(ph, 0):
+                peak[ph] = len(live)
+    loop = max(back_edges, key=lambda e: e[0] - e[1]) if back_edges else None
+    if loop and loop[0] - loop[1] >= 1000:
+        head = live_in[block_of[loop[1]]]
+        print(f"cycle loop: instructions {loop[1]}..{loop[0]}, {len(head)} VGPRs live at its head: " + " ".join(f"v{r}" for r in sorted(head)))
     order = []
     for ph, _, _ in ins:
         if ph not in order:

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Build gate for EVERY shipped kernel instantiation (ukf_kernel16 and the generic ukf_kernel): no scratch and no AGPRs.
+"""Build gate for EVERY shipped kernel instantiation (ukf_kernel16 and the generic ukf_kernel): no scratch and no AGPRs, and
+the tuned kernels keep the wavefronts per SIMD their design counts on (fp64: three, fp32: five) -- a register regression
+that costs a wavefront fails the build instead of showing up as a slower bench line.
 
 ROCm 7.2's hipcc places VGPR spill / live-range-split copies at the join label of a divergent `if`
 in front of the EXEC restore; reached through s_cbranch_execz they save nothing (see the note in
@@ -30,7 +32,7 @@ def parse(text):
 def main(paths):
     # --allow-agpr: diagnostic builds with the fp64 one-wavefront-per-filter kernels (make GENERIC_F64=1)
     allow_agpr = "--allow-agpr" in paths
-    paths = [p for p in paths if p != "--allow-agpr"]
+    paths = [p for p in paths if not p.startswith("--")]
     bad, rows = [], []
     for p in paths:
         for k in parse(open(p).read()):
@@ -44,6 +46,14 @@ def main(paths):
               f"occ={k.get('occupancy')}")
     if bad:
         print("ERROR: kernels with scratch or AGPR spills (unsafe with this toolchain):", [b["name"] for b in bad])
+        return 1
+    # occupancy floor of the tuned kernels (the register side; LDS is checked by the layout's static_asserts):
+    # ukf_kernel16<double, ...> three wavefronts per SIMD (<= 168 VGPRs), ukf_kernel16<float, ...> five (<= 96)
+    slow = [k for k in rows if "ukf_kernel16I" in k["name"] and
+            k.get("occupancy", 0) < (3 if "ukf_kernel16Id" in k["name"] else 5)]
+    if slow and "--no-occupancy-floor" not in sys.argv:
+        print("ERROR: tuned kernels below their occupancy floor (fp64: 3, fp32: 5 wavefronts per SIMD):",
+              [(k["name"], k.get("vgpr"), k.get("occupancy")) for k in slow])
         return 1
     return 0
 

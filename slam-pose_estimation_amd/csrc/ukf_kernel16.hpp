@@ -721,10 +721,19 @@ template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
 // workgroup (64-bit arithmetic on the scalar unit) plus a small 32-bit lane offset, instead of a 64-bit multiply-add per
 // lane and stream (8 v_mad_u64_u32, 2 v_mul_lo_u32, 7 v_lshl_add_u64 per wavefront; 45 instructions fewer in all).  Measured:
 // +0.7 % fp64, nothing in fp32 -- the prologue is not where a wavefront's time goes.
-template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false>
+// PLAINL ("plain launch": single fused cycle, direct): what the host knows about a launch of the common fixed-rate case becomes the kernel's TYPE --
+// one time step and one measurement model for the whole launch, no per-filter timestamps / time steps / model ids / activity
+// flags, the accept-any gate of the reference (PoseUKF.cpp:116), a fresh status word; for PoseWithVelocity the model is one
+// of the three full 3-vector selections (position, velocity, angular velocity).  The other measurement paths, the gate
+// arithmetic on per-filter streams and their loads are not in this kernel at all: 136 instead of 140 VGPRs (fp64 Pose), much less
+// code: +3.0 % on the fp64 headline, +2.8 % fp32, +2.5 % config 4, +2 % OrientationState fp64 (same-box A/B, DESIGN.md
+// section 4.10).  The launcher picks it when all of that holds
+// (ukf_launch.inc.hpp); the arithmetic of a filter is the general kernel's, bit for bit (tests/test_gpu_plain_kernel.py).
+template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false, bool PLAINL = false>
 __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(const KArgs<T> a) {
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
     static_assert(!INDIRECT || (DO_PREDICT && DO_UPDATE && !MULTI), "indirect launches run the single fused cycle");
+    static_assert(!PLAINL || (DO_PREDICT && DO_UPDATE && !MULTI && !INDIRECT), "plain launches run the single fused cycle, directly");
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
     constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
@@ -747,9 +756,12 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     // a kernel argument: the loads of an argument inside the cycle loop are not the load the assumption was made about, and
     // the timestamp path stayed alive in the multi-cycle kernels -- registers around the whole loop, and a wavefront per SIMD
     // in the OrientationState fp64 kernel).
-    const int64_t* const a_ts = MULTI ? nullptr : a.ts;
-    const double* const a_dt = MULTI ? nullptr : a.dt;
-    const uint8_t* const a_active = MULTI ? nullptr : a.active;
+    const int64_t* const a_ts = (MULTI || PLAINL) ? nullptr : a.ts;
+    const double* const a_dt = (MULTI || PLAINL) ? nullptr : a.dt;
+    const uint8_t* const a_active = (MULTI || PLAINL) ? nullptr : a.active;
+    const int32_t* const a_meas = PLAINL ? nullptr : a.meas;
+    const T gate_chi2_c = PLAINL ? T(-1) : a.gate_chi2;
+    const bool status_accumulate_c = PLAINL ? false : (a.status_accumulate != 0);
     if constexpr (MULTI) {
         // multi-cycle launches are direct launches with one dt per cycle for every filter (checked by the host): no
         // per-filter timestamps, time steps, activity flags or filter index list to keep alive
@@ -802,7 +814,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     const T* const in_b_p = at_wg(a.in_b, 3);
     const int64_t* const ts_p = at_wg(a_ts, 1);
     const double* const dt_p = at_wg(a_dt, 1);
-    const int32_t* const meas_p = at_wg(a.meas, 1);
+    const int32_t* const meas_p = at_wg(a_meas, 1);
     const uint8_t* const active_p = at_wg(a_active, 1);
     const T* const z_p = at_wg(a.z, 3);
     const IDX q_stride = (!MULTI && a.q_uniform) ? 0 : 9;     // batch-uniform measurement covariance: every filter reads the same 9 scalars
@@ -1023,8 +1035,8 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     bool do_u = false;
     int mid = -1;
     if constexpr (DO_UPDATE) {
-        mid = a.meas ? mid_l : meas_uniform_c;
-        const bool act = M::meas_valid(mid) && (a_active ? act_b != 0 : true);
+        mid = a_meas ? mid_l : meas_uniform_c;
+        const bool act = PLAINL ? true : (M::meas_valid(mid) && (a_active ? act_b != 0 : true));   // (plain: the launcher checked the model id)
         do_u = live && act && !p_error && !noev;
         // (a scheduled prediction-only cycle of a multi-cycle launch is a plain predictionStep: no INACTIVE mark)
         const bool predict_only = MULTI && a.cyc_sched != 0 && meas_uniform_c < 0;
@@ -1639,8 +1651,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 do_u = do_u && fin;
             }
             const int midc = M::meas_valid(mid) ? mid : (M::MODEL == 0 ? 0 : 9);
-            const int m = M::meas_dim(midc);
-            const bool so3 = M::meas_is_so3(midc);
+            // (plain launches: a full 3-vector Euclidean selection for PoseWithVelocity, the body velocity for OrientationState)
+            const int m = PLAINL ? 3 : M::meas_dim(midc);
+            const bool so3 = PLAINL ? false : M::meas_is_so3(midc);
             const bool need_q = so3 || (M::MODEL == 1);
             // Measurement statistics: S (innovation covariance), cx (row l of Sigma_xz), innovation.
             bool ok1 = true, zconv = true;
@@ -1666,7 +1679,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 // position, velocity or angular velocity: three consecutive tangent components from a scalar base,
                 // so every index below is scalar arithmetic and nothing needs a select.
                 const int mu_id = meas_uniform_c;
-                const bool uni3 = (a.meas == nullptr) && (mu_id == 0 || mu_id == 4 || mu_id == 8);
+                const bool uni3 = PLAINL || ((a_meas == nullptr) && (mu_id == 0 || mu_id == 4 || mu_id == 8));
                 if (uni3) {
                     const int tb = (mu_id == 0) ? 0 : ((mu_id == 4) ? 6 : 9);   // first tangent index
                     const int sb = tb + ((tb >= Q) ? 1 : 0);                       // first stored index
@@ -1891,7 +1904,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) maha += innov[r] * Si[r * 3 + c] * innov[c];
-                accept = (a.gate_chi2 < T(0)) || (maha <= a.gate_chi2);
+                accept = (gate_chi2_c < T(0)) || (maha <= gate_chi2_c);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) Kr[c] = cx[0] * Si[c] + cx[1] * Si[3 + c] + cx[2] * Si[6 + c];
 #pragma unroll
@@ -2100,7 +2113,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         }
         if (l < S) *at(mu_c, fcc * S + IDX(l)) = MUS[l];
     }
-    if (fvalid && l == 0) *at(status_c, fcc) = a.status_accumulate ? (*at(status_c, fcc) | st) : st;
+    if (fvalid && l == 0) *at(status_c, fcc) = status_accumulate_c ? (*at(status_c, fcc) | st) : st;
 }
 
 }  // namespace ukfb

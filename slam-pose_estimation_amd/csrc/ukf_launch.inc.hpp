@@ -113,7 +113,14 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     static const int lds_pad = [] { const char* s = std::getenv("UKFB_LDS_PAD_BYTES"); return s ? std::atoi(s) : 0; }();
     const int lds = FPW * lds_bytes_per_filter16<T, M>() + lds_pad;
     const bool multi = r.cycles > 0;   // ukfb_cycle_multi_dev: fused cycles only (checked by the caller)
-    const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : "cycle") : "predict") : "update");
+    // the plain instantiation (ukf_kernel16<..., PLAINL>): everything the kernel may then take as a compile-time fact
+    const char* const plain_env = std::getenv("UKFB_NO_PLAIN_KERNEL");   // (A/B and tests: =1 keeps the general kernel; read per launch)
+    const bool plain_off = plain_env && plain_env[0] == '1';
+    const bool plain = !plain_off && !multi && r.do_predict && r.do_update && !args.fidx && !args.ts && !args.dt && !args.meas && !args.active &&
+                       !args.status_accumulate && args.gate_chi2 < T(0) &&
+                       (M::MODEL != 0 ? args.meas_uniform == 9
+                                      : (args.meas_uniform == 0 || args.meas_uniform == 4 || args.meas_uniform == 8));
+    const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : (plain ? "cycle-plain" : "cycle")) : "predict") : "update");
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
                      (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
     e->last_lds = lds;
@@ -141,6 +148,7 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
             hipLaunchKernelGGL(kern, g2, bd, lds, sb, h2);
         };
         if (multi) go(ukf_kernel16<T, M, true, true, true>);
+        else if (plain) go(ukf_kernel16<T, M, true, true, false, false, true>);
         else if (r.do_predict && r.do_update) go(ukf_kernel16<T, M, true, true>);
         else if (r.do_predict) go(ukf_kernel16<T, M, true, false>);
         else go(ukf_kernel16<T, M, false, true>);
@@ -160,6 +168,8 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
     } else if (multi)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
+    else if (plain)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, false, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)

@@ -34,7 +34,9 @@ def kernel_ns(d, kernel_substr):
 
 # DPP-fused fp32 arithmetic on the default path of each kernel (static listing, tools/isa_phases.py -DUKFB_ASSUME_HEADLINE):
 # the SQ counts them as FMA / ADD, the SIMD issues them at the 4-cycle rate
-DPP_FUSED_F32 = {"ukf_kernel16<f32,pose,cycle>": 243.0, "ukf_kernel16<f32,orient,cycle>": 300.0}
+DPP_FUSED_F32 = {"ukf_kernel16<f32,pose,cycle>": 243.0, "ukf_kernel16<f32,orient,cycle>": 300.0,
+                 # (the plain-launch instantiations run the same factorisations)
+                 "ukf_kernel16<f32,pose,cycle-plain>": 243.0, "ukf_kernel16<f32,orient,cycle-plain>": 300.0}
 
 calib = {}
 for prec in ("f64", "f32"):

@@ -721,7 +721,7 @@ template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
 // workgroup (64-bit arithmetic on the scalar unit) plus a small 32-bit lane offset, instead of a 64-bit multiply-add per
 // lane and stream (8 v_mad_u64_u32, 2 v_mul_lo_u32, 7 v_lshl_add_u64 per wavefront; 45 instructions fewer in all).  Measured:
 // +0.7 % fp64, nothing in fp32 -- the prologue is not where a wavefront's time goes.
-// PLAINL ("plain launch": single fused cycle, direct): what the host knows about a launch of the common fixed-rate case becomes the kernel's TYPE --
+// PLAINL ("plain launch": fused cycles, direct; also as a multi-cycle launch without a schedule): what the host knows about a launch of the common fixed-rate case becomes the kernel's TYPE --
 // one time step and one measurement model for the whole launch, no per-filter timestamps / time steps / model ids / activity
 // flags, the accept-any gate of the reference (PoseUKF.cpp:116), a fresh status word; for PoseWithVelocity the model is one
 // of the three full 3-vector selections (position, velocity, angular velocity).  The other measurement paths, the gate
@@ -733,7 +733,7 @@ template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false,
 __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(const KArgs<T> a) {
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
     static_assert(!INDIRECT || (DO_PREDICT && DO_UPDATE && !MULTI), "indirect launches run the single fused cycle");
-    static_assert(!PLAINL || (DO_PREDICT && DO_UPDATE && !MULTI && !INDIRECT), "plain launches run the single fused cycle, directly");
+    static_assert(!PLAINL || (DO_PREDICT && DO_UPDATE && !INDIRECT), "plain launches run fused cycles, directly");
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
     constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
@@ -967,8 +967,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         has_ctr = l == D;
         // the same for the two launch-wide scalars whose derivatives (time gate, selection tables of the measurement
         // model) are evaluated with vector instructions: opaque scalar moves
-        dt_uniform_c = a.cyc_sched ? a.cyc_dt[cyc] : a.dt_uniform;          // (a schedule: this cycle's own dt and model)
-        meas_uniform_c = a.cyc_sched ? a.cyc_model[cyc] : a.meas_uniform;
+        // (a schedule: this cycle's own dt and model; a plain multi-cycle launch has none)
+        dt_uniform_c = (!PLAINL && a.cyc_sched) ? a.cyc_dt[cyc] : a.dt_uniform;
+        meas_uniform_c = (!PLAINL && a.cyc_sched) ? a.cyc_model[cyc] : a.meas_uniform;
         asm volatile("" : "+s"(dt_uniform_c));
         asm volatile("" : "+s"(meas_uniform_c));
     }
@@ -1039,7 +1040,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         const bool act = PLAINL ? true : (M::meas_valid(mid) && (a_active ? act_b != 0 : true));   // (plain: the launcher checked the model id)
         do_u = live && act && !p_error && !noev;
         // (a scheduled prediction-only cycle of a multi-cycle launch is a plain predictionStep: no INACTIVE mark)
-        const bool predict_only = MULTI && a.cyc_sched != 0 && meas_uniform_c < 0;
+        const bool predict_only = MULTI && !PLAINL && a.cyc_sched != 0 && meas_uniform_c < 0;
         st |= (live && !do_u && !predict_only) ? ST_INACTIVE : 0u;
     }
     wsync();

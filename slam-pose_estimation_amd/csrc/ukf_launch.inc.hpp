@@ -116,11 +116,11 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     // the plain instantiation (ukf_kernel16<..., PLAINL>): everything the kernel may then take as a compile-time fact
     const char* const plain_env = std::getenv("UKFB_NO_PLAIN_KERNEL");   // (A/B and tests: =1 keeps the general kernel; read per launch)
     const bool plain_off = plain_env && plain_env[0] == '1';
-    const bool plain = !plain_off && !multi && r.do_predict && r.do_update && !args.fidx && !args.ts && !args.dt && !args.meas && !args.active &&
+    const bool plain = !plain_off && (!multi || !args.cyc_sched) && r.do_predict && r.do_update && !args.fidx && !args.ts && !args.dt && !args.meas && !args.active &&
                        !args.status_accumulate && args.gate_chi2 < T(0) &&
                        (M::MODEL != 0 ? args.meas_uniform == 9
                                       : (args.meas_uniform == 0 || args.meas_uniform == 4 || args.meas_uniform == 8));
-    const char* mode = multi ? "multicycle" : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : (plain ? "cycle-plain" : "cycle")) : "predict") : "update");
+    const char* mode = multi ? (plain ? "multicycle-plain" : "multicycle") : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : (plain ? "cycle-plain" : "cycle")) : "predict") : "update");
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
                      (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
     e->last_lds = lds;
@@ -147,7 +147,8 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
             hipLaunchKernelGGL(kern, g1, bd, lds, sa, h1);
             hipLaunchKernelGGL(kern, g2, bd, lds, sb, h2);
         };
-        if (multi) go(ukf_kernel16<T, M, true, true, true>);
+        if (multi && plain) go(ukf_kernel16<T, M, true, true, true, false, true>);
+        else if (multi) go(ukf_kernel16<T, M, true, true, true>);
         else if (plain) go(ukf_kernel16<T, M, true, true, false, false, true>);
         else if (r.do_predict && r.do_update) go(ukf_kernel16<T, M, true, true>);
         else if (r.do_predict) go(ukf_kernel16<T, M, true, false>);
@@ -166,7 +167,9 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
             return UKFB_ERR_INVALID_ARG;
         }
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
-    } else if (multi)
+    } else if (multi && plain)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true, false, true>), gd, bd, lds, main_stream(e), args);
+    else if (multi)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
     else if (plain)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, false, true>), gd, bd, lds, main_stream(e), args);

@@ -49,14 +49,20 @@ def test_pose_plain_launch_equals_the_general_kernel(spe, prec, n):
             names.append(e.last_launch_info()["kernel"])
         e.cycle_dev(0.01, spe.MEAS_POS_XY, z_by_model[spe.MEAS_POS3], Q_t)      # not a full 3-vector: the general kernel
         names.append(e.last_launch_info()["kernel"])
+        # three cycles in one launch (no schedule): the plain multi-cycle instantiation
+        z3 = torch.stack([z_by_model[spe.MEAS_VEL3]] * 2).contiguous()
+        Q3 = torch.stack([Q_t] * 2).contiguous()
+        torch.cuda.synchronize()
+        e.cycle_multi_dev(3, 0.01, spe.MEAS_VEL3, z3, Q3, 2, 1)
+        names.append(e.last_launch_info()["kernel"])
         m, c, _ = e.state()
         st = e.status()
         e.close()
         return m, c, st, names
 
     (m1, c1, st1, names1), (m0, c0, st0, names0) = _twice(run)
-    assert all(k.endswith("cycle-plain>") for k in names1[:4]) and names1[4].endswith(",cycle>")
-    assert all(k.endswith(",cycle>") for k in names0)
+    assert all(k.endswith(",cycle-plain>") for k in names1[:4]) and names1[4].endswith(",cycle>") and names1[5].endswith(",multicycle-plain>")
+    assert all(k.endswith(",cycle>") for k in names0[:5]) and names0[5].endswith(",multicycle>")
     assert np.array_equal(m1, m0, equal_nan=True) and np.array_equal(c1, c0, equal_nan=True) and (st1 == st0).all()
     assert (st1[5] & spe.ST_ERR_CHOLESKY) and (st1[n - 1] & spe.ST_UNINITIALISED) and st1[6] == 0
     assert np.isfinite(m1[:n - 2]).all() and not np.array_equal(m1[:5], mu[:5])
@@ -82,6 +88,10 @@ def test_orientation_plain_launch_equals_the_general_kernel(spe, prec):
         for _ in range(3):
             e.cycle_dev(0.01, spe.MEAS_ORIENT_BODYVEL3, z_t, Q_t)
         name = e.last_launch_info()["kernel"]
+        z2, Q2 = torch.stack([z_t] * 2).contiguous(), torch.stack([Q_t] * 2).contiguous()
+        torch.cuda.synchronize()
+        e.cycle_multi_dev(4, 0.01, spe.MEAS_ORIENT_BODYVEL3, z2, Q2, 2, 0)
+        assert e.last_launch_info()["kernel"].endswith("multicycle-plain>" if name.endswith("plain>") else "multicycle>")
         m, c, _ = e.state()
         st = e.status()
         e.close()

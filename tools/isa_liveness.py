@@ -6,7 +6,7 @@ dataflow to its fixpoint and prints the maximum number of simultaneously live VG
 where the register budget is spent -- and, for a multi-cycle kernel, what is live at the head of the cycle loop.  Exec-masked
 writes are treated as full definitions (an under-estimate where a divergent region writes part of a register).
 
-usage: tools/isa_liveness.py [pose|orient] [f64|f32] [cycle|predict|update|multi] [extra hipcc flags...]"""
+usage: tools/isa_liveness.py [pose|orient] [f64|f32] [cycle|predict|update|multi|indirect|plain|multi-plain] [extra hipcc flags...]"""
 import os
 import re
 import subprocess
@@ -39,7 +39,8 @@ def main():
                                "-mllvm", "-disable-machine-licm", "-DUKFB_PHASE_MARKS", "-S", "--cuda-device-only", "-o", out, tu] + extra,
                               stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
-    flags = {"cycle": "Lb1ELb1ELb0ELb0E", "predict": "Lb1ELb0ELb0ELb0E", "update": "Lb0ELb1ELb0ELb0E", "multi": "Lb1ELb1ELb1ELb0E"}[mode]
+    flags = {"cycle": "Lb1ELb1ELb0ELb0ELb0E", "predict": "Lb1ELb0ELb0ELb0ELb0E", "update": "Lb0ELb1ELb0ELb0ELb0E", "multi": "Lb1ELb1ELb1ELb0ELb0E",
+             "indirect": "Lb1ELb1ELb0ELb1ELb0E", "plain": "Lb1ELb1ELb0ELb0ELb1E", "multi-plain": "Lb1ELb1ELb1ELb0ELb1E"}[mode]
     start = next(i for i, l in enumerate(text) if l.startswith("_ZN4ukfb12ukf_kernel16") and flags in l and ":" in l)
     ins = []   # (phase, defs, uses)
     cur = "entry"

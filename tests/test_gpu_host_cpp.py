@@ -66,3 +66,20 @@ def test_host_cpp_classes_match_the_oracle(oracle, onp):
     g = 9.7803267714 * ((1 + 0.00193185138639 * math.sin(lat) ** 2) / math.sqrt(1 - 0.0818191908426 ** 2 * math.sin(lat) ** 2))
     g *= (6378137.0 / (6378137.0 + alt)) ** 2
     assert abs(r["wgs84"] - g) < 1e-12
+
+
+def test_cabi_bench_runs_the_headline_loop_from_cpp():
+    """tests/cpp/cabi_bench.cpp: the bench loop (device-resident samples, ukfb_cycle_dev, HIP-event timing) from a C++ host with
+    nothing but include/ukf_batch.h -- one engine, and a two-shard ukfb_group on the same device.  Small here; the full-size
+    lines are in profiles/ (tools/gpu_bench.sh cabi)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "cabi_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    for args, kernel in (["16384", "40", "f64"], "ukf_kernel16<f64,pose,cycle-plain>"), (["16384", "40", "f32"], "ukf_kernel16<f32,pose,cycle-plain>"), \
+            (["16387", "40", "f64", "2"], None):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr + out.stdout
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        assert r["status_or"] == 0 and r["filter_cycles_per_s"] > 1e7 and r["cycles"] == 40
+        if kernel:
+            assert r["kernel"] == kernel

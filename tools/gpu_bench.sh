@@ -31,5 +31,6 @@ for what in "$@"; do
     track_1000) run track_1000 --no-cpu-baseline --steps 1000 --no-extra-regions --inputs tracking ;;
     group2) run group2 --no-cpu-baseline --launcher group --gpus 2 --group-devices 0,0 ;;
     full) run full ;;
+    cabi) make -s -C tests/cpp build/cabi_bench 2>/dev/null; for a in "1048576 500 f64" "1048576 500 f32" "131072 500 f64" "1048576 500 f64 2"; do tests/cpp/build/cabi_bench $a | tee -a $out/cabi.txt; done ;;
   esac
 done

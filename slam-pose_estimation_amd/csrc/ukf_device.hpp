@@ -61,27 +61,23 @@ UKFB_DEV double fast_rsqrt(double x) {
     const double e = fma(-(x * r), r, 1.0);
     return fma(0.5 * r, e, r);
 }
-// UKFB_F32_NEWTON (diagnostic / attribution switch, tests/drift_f32.py): 1 = one Newton step on the fp32 seeds as well
-#ifndef UKFB_F32_NEWTON
-#define UKFB_F32_NEWTON 0
-#endif
-UKFB_DEV float fast_rsqrt(float x) {
-    float r = __builtin_amdgcn_rsqf(x);
-    if constexpr (UKFB_F32_NEWTON != 0) {
-        const float e = fmaf(-(x * r), r, 1.0f);
-        r = fmaf(0.5f * r, e, r);
-    }
-    return r;
-}
+// (a Newton step on the fp32 seeds does not move the fp32 engine's distance to the fp64 oracle: profiles/r03_f32_drift_attribution.txt)
+UKFB_DEV float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 UKFB_DEV double fast_rcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
-UKFB_DEV float fast_rcp(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
-    if constexpr (UKFB_F32_NEWTON != 0) r = fmaf(fmaf(-x, r, 1.0f), r, r);
-    return r;
-}
+UKFB_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// -DUKFB_COUNTS (diagnostic build, tools/trip_counts.py): how often a wavefront takes the wide-angle paths of exp / log.
+// One atomic per wavefront and call; the product build defines nothing and the macro vanishes.
+#if defined(UKFB_COUNTS)
+enum { DBG_EXP = 0, DBG_EXP_LARGE, DBG_EXP_BIG, DBG_LOGN, DBG_LOGN_BIG, DBG_LOG, DBG_LOG_BIG, DBG_N };
+static __device__ unsigned long long ukfb_dbg[DBG_N];
+#define UKFB_DBG_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&ukfb_dbg[i], 1ull); } while (0)
+#else
+#define UKFB_DBG_COUNT(i) do { } while (0)
+#endif
 
 // Near-minimax polynomials (Chebyshev fits computed with mpmath at 50 digits; max abs error quoted) for
 //   cos(sqrt(y)), sin(sqrt(y))/sqrt(y) on 0 <= y <= 0.62   and   atan(sqrt(u))/sqrt(u) on 0 <= u <= 0.07.
@@ -125,21 +121,8 @@ template <class T, int N> UKFB_DEV T horner(const T (&c)[N + 1], T x) {
         r = fma(r, x, c_[1]);                                           \
         r = fma(r, x, c_[0]);                                           \
     } while (0)
-// UKFB_F32_POLY_HI (diagnostic / attribution switch): 1 = the fp32 engines evaluate the fp64 fits (coefficients rounded to float)
-#ifndef UKFB_F32_POLY_HI
-#define UKFB_F32_POLY_HI 0
-#endif
-template <int N> UKFB_DEV float horner_from_double(const double (&c)[N + 1], float x) {
-    float r = float(c[N]);
-#pragma unroll
-    for (int k = N - 1; k >= 0; --k) r = fmaf(r, x, float(c[k]));
-    return r;
-}
 template <class T> UKFB_DEV void poly_cos_sinc(T y, T& c, T& s) {
-    if constexpr (sizeof(T) == 4 && UKFB_F32_POLY_HI != 0) {
-        c = horner_from_double<Poly<double>::NC>(Poly<double>::COS, y);
-        s = horner_from_double<Poly<double>::NS>(Poly<double>::SINC, y);
-    } else if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4) {
         static_assert(Poly<float>::NC == 4 && Poly<float>::NS == 3, "literal Horner forms");
         UKFB_HORNER_LIT(Poly<float>::COS, 4, y, c);
         UKFB_HORNER_LIT(Poly<float>::SINC, 3, y, s);
@@ -149,9 +132,7 @@ template <class T> UKFB_DEV void poly_cos_sinc(T y, T& c, T& s) {
     }
 }
 template <class T> UKFB_DEV T poly_atan_ratio(T u) {
-    if constexpr (sizeof(T) == 4 && UKFB_F32_POLY_HI != 0) {
-        return horner_from_double<Poly<double>::NA>(Poly<double>::ATAN, u);
-    } else if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4) {
         static_assert(Poly<float>::NA == 3, "literal Horner form");
         T r;
         UKFB_HORNER_LIT(Poly<float>::ATAN, 3, u, r);
@@ -183,9 +164,12 @@ template <class T> UKFB_DEV void cos_sinc_fast(T y, T& c, T& s) {
     const bool big = !(y <= T(4) * Poly<T>::Y_SMALL);
     T yy = y;
     T ratio = T(1);
+    UKFB_DBG_COUNT(DBG_EXP);
     if (any_large) {
+        UKFB_DBG_COUNT(DBG_EXP_LARGE);
         yy = small ? y : T(0.25) * y;
         if (wave_any(big)) {
+            UKFB_DBG_COUNT(DBG_EXP_BIG);
             const T rs = fast_rsqrt(big ? y : T(1));         // 1/x
             const T x = y * rs;
             const T k = m_rint(x * TwoPi<T>::inv);
@@ -227,7 +211,9 @@ template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
     const T u = v2 * rw * rw;
     T s = T(2) * rw * poly_atan_ratio(u);
     const bool big = !(u <= Poly<T>::U_SMALL);
+    UKFB_DBG_COUNT(DBG_LOG);
     if (wave_any(big)) {
+        UKFB_DBG_COUNT(DBG_LOG_BIG);
         const T n2 = fma(w, w, v2);
         const T n = n2 * fast_rsqrt(n2);
         const T r1 = fast_rcp(m_abs(w) + n);
@@ -258,7 +244,9 @@ template <class T> UKFB_DEV void so3_log_fast_n(const T (&q)[4], T nrm, T (&r)[3
     const T t1 = v2 * r1 * r1;                           // tan^2(phi/2)
     T s = T(4) * r1 * poly_atan_ratio(t1);
     const bool big = !(t1 <= Poly<T>::U_SMALL);          // also w + |q| <= 0 (angle >= pi) and NaN
+    UKFB_DBG_COUNT(DBG_LOGN);
     if (wave_any(big)) {
+        UKFB_DBG_COUNT(DBG_LOGN_BIG);
         const T r1b = fast_rcp(m_abs(w) + nrm);
         const T t1b = v2 * r1b * r1b;                    // tan^2(phi/2) <= 1 with phi = atan(|vec| / |w|)
         const T q2 = T(1) + t1b;

@@ -92,8 +92,8 @@ template <class T> struct KArgs {
     int cyc_sched;
     int32_t cyc_model[UKFB_MAX_MULTI_CYCLES];
     double cyc_dt[UKFB_MAX_MULTI_CYCLES];
-#ifdef UKFB_STAMPS
-    unsigned long long* stamps;  // diagnostic build: [grid][UKFB_MAX_STAMPS] s_memtime per phase marker
+#if defined(UKFB_STAMPS) || defined(UKFB_COUNTS)
+    unsigned long long* stamps;  // diagnostic builds: [grid][UKFB_MAX_STAMPS] s_memtime per phase marker (UKFB_STAMPS) / value + 1 per counter slot (UKFB_COUNTS)
 #endif
 };
 #define UKFB_MAX_STAMPS 32

@@ -40,9 +40,9 @@
 //  * round 3: model-class buckets (KArgs::fidx_inputs: an indirect launch over a filter list grouped by update class, the
 //    per-call inputs indexed by the filter, -1 entries = padding); split launches (KArgs::item0: a direct launch as two half
 //    launches on two streams); the OrientationState fp64 slice trimmed to 11 workgroups per CU (Layout16::ORIENT64_TRIM,
-//    SINK_IN_NSH, LAF_PAD: every LDS scalar a kernel reads is one it wrote -- tests/test_gpu_lds_leftovers.py); and, default
-//    OFF because it measured slower, the fp64 Pose variant for four wavefronts per SIMD (UKFB_COMPACT64 + UKFB_LATE_XM:
-//    Layout16::COMPACT, the minus sigma point formed late -- DESIGN.md section 8).
+//    SINK_IN_NSH, LAF_PAD: every LDS scalar a kernel reads is one it wrote -- tests/test_gpu_lds_leftovers.py).
+//  * measured-and-rejected variants (the four-wavefront fp64 slice, the late minus point, Newton steps on the fp32 seeds, ...)
+//    are NOT in this header: tools/variants/ holds them as patches that tools/build_variant.sh applies to a scratch copy.
 //
 // TOOLCHAIN NOTE (ROCm 7.2 hipcc, -O2/-O3): when this kernel needed VGPR spills / live-range
 // splits, the compiler placed the copies at the join label of a divergent `if` BEFORE the
@@ -86,11 +86,6 @@ template <int C> UKFB_DEV void fmac_bcast(double& acc, double src, double m) {
 template <int C> UKFB_DEV float rcp_bcast(float v) {
     float r;
     asm volatile("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(C));
-    if constexpr (UKFB_F32_NEWTON != 0) {   // r += r (1 - v_C r): the residual reads lane C's pivot through DPP as well
-        float e = 1.0f;
-        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(e) : "v"(v), "v"(-r), "n"(C));
-        r = fmaf(e, r, r);
-    }
     return r;
 }
 // (fp64: the assembler accepts v_rcp_f64_dpp, the hardware does not broadcast for it -- every pivot came out wrong; the move stays)
@@ -225,21 +220,8 @@ template <class T> struct MT<OrientM<T>> {
     }
 };
 
-#ifndef UKFB_ISO_TOL_F32
-#define UKFB_ISO_TOL_F32 1e-4   // | |q|^2 - 1 | up to which an isotropic noise block is not rotated (fp32 engines)
-#endif
-#ifndef UKFB_COMPACT64
-#define UKFB_COMPACT64 0  // 1 (with UKFB_LATE_XM=1): fp64 Pose on the compact 316-scalar LDS slice (Layout16::COMPACT), 4 wavefronts per SIMD -- measured and rejected; 0: the plain 396-scalar slice
-#endif
-#ifndef UKFB_ORIENT64_TRIM
-#define UKFB_ORIENT64_TRIM 1   // 0: the OrientationState fp64 slice of round 2 (14 656 B, 10 workgroups per CU)
-#endif
-#ifndef UKFB_PREFETCH_ORIENT64
-#define UKFB_PREFETCH_ORIENT64 1   // 0: the OrientationState fp64 multi-cycle kernel loads every cycle's inputs itself (as the fp32 kernels do)
-#endif
-#ifndef UKFB_F32_TRIM
-#define UKFB_F32_TRIM 1   // 0: the fp32 Pose slice as before round 2's last trim (424 floats, 21 workgroups per CU): -2.7 %
-#endif
+// | |q|^2 - 1 | up to which an isotropic noise block is not rotated (fp32 engines; 1e-9 in fp64)
+constexpr float ISO_TOL_F32 = 1e-4f;
 template <class T, class M> struct Layout16 {
     static constexpr int VEC = 16 / int(sizeof(T));
     static constexpr int D = M::D, S = M::S, N = 2 * D + 1, PK = D * (D + 1) / 2;
@@ -264,28 +246,14 @@ template <class T, class M> struct Layout16 {
     static constexpr int TNL = (D * LS > N * ST) ? (D * LS - N * ST) : 0;
     // OrientationState fp64 (round 3): the same two trims bring its slice from 14 656 B to 14 016 B = 11 instead of 10
     // one-wave workgroups per CU (11 LDS allocation granules of 1 280 B; its 146 VGPRs allow 12)
-    static constexpr bool ORIENT64_TRIM = (M::MODEL == 1 && sizeof(T) == 8 && UKFB_ORIENT64_TRIM != 0);
-    static constexpr bool LAF_ROW_D = !((M::MODEL == 0 && (sizeof(T) == 8 || UKFB_F32_TRIM)) || ORIENT64_TRIM);
+    static constexpr bool ORIENT64_TRIM = (M::MODEL == 1 && sizeof(T) == 8);
+    static constexpr bool LAF_ROW_D = !(M::MODEL == 0 || ORIENT64_TRIM);
     // fp32 Pose: the small regions packed to 8-byte instead of 16-byte boundaries bring the slice to 400 floats = 6400 B =
     // 5 allocation granules: 24 workgroups per CU = 6 wavefronts per SIMD (77 VGPRs allow it)
-    static constexpr int alm(int x) { return (M::MODEL == 0 && sizeof(T) == 4 && UKFB_F32_TRIM) ? (x + 1) / 2 * 2 : al(x); }
-    // COMPACT (fp64 Pose, round 3): the slice at 316 scalars = 10 112 B per wavefront, under the 10 240 B that 16 one-wave
-    // workgroups per CU = FOUR wavefronts per SIMD need (LDS allocation granule 1 280 B).  Against the plain layout (396):
-    //  * the staged covariance is split: its affine triangle (rows / columns >= NL, 21 entries, the block the prediction
-    //    updates in place) in AFF, the nonlinear triangle and the cross block (57 entries) in REST -- and the scaled affine
-    //    factor rows LAF (72) ALIAS REST: between the prediction's row loads and its tile stores those 57 entries are dead
-    //    (a filter that does not commit keeps them: its LAF rows go to the sink);
-    //  * the rotation matrix of the mean lives in the head of the factor region (free once every lane holds its column and
-    //    the transposition buffer is done: it is written in p_delta_e, not before the factorisation);
-    //  * the store sink IS the shaped-noise region (the only sink store between that table's fill and its fetch is the
-    //    fill's own, which goes to the table's spare slot).
-    static constexpr bool COMPACT = (M::MODEL == 0 && sizeof(T) == 8 && UKFB_COMPACT64 != 0);
-    static constexpr int NAFF = (D - NL) * (D - NL + 1) / 2, NTRI = NL * (NL + 1) / 2, NREST = PK - NAFF;
+    static constexpr int alm(int x) { return (M::MODEL == 0 && sizeof(T) == 4) ? (x + 1) / 2 * 2 : al(x); }
     static constexpr int UEND = al(TNL + (N + 1) * ST);     // end of the factor / delta-table region
-    static constexpr int PKS = UEND;                        // plain: PKP scalars, packed lower triangle (survives the prediction)
-    static constexpr int AFF = UEND;                        // compact: affine triangle, local packed order
-    static constexpr int REST = AFF + al(NAFF);             // compact: nonlinear triangle (local packed order), then the cross block [r - NL][c]
-    static constexpr int LAF = COMPACT ? REST : (PKS + PKP);   // (D+1)*ST : row l = scaled affine rows of column l of the factor.  Where !LAF_ROW_D its zero row D
+    static constexpr int PKS = UEND;                        // PKP scalars, packed lower triangle (survives the prediction)
+    static constexpr int LAF = PKS + PKP;                   // (D+1)*ST : row l = scaled affine rows of column l of the factor.  Where !LAF_ROW_D its zero row D
                                                             // (read by the cross lanes in their last trip) is not stored: it aliases the
                                                             // mean staging behind it - finite values that meet the table's exact-zero row
     static constexpr int LAF_SZ = al((D + (LAF_ROW_D ? 1 : 0)) * ST);
@@ -294,27 +262,21 @@ template <class T, class M> struct Layout16 {
     // Uninitialised LDS times the table's exact zero is NaN if the leftover happens to be NaN or Inf: the pad is zeroed with
     // the factor rows (found by tests/fuzz_parity.py as a box-dependent Cholesky failure of one OrientationState filter).
     static constexpr int LAF_PAD = LAF_ROW_D ? 0 : (LAF_SZ - D * ST);
-    static_assert(!COMPACT || (LAF_SZ >= NREST && !LAF_ROW_D), "compact layout: LAF covers REST and is followed by the mean staging");
     static constexpr int MISC = LAF + LAF_SZ;
     static constexpr int MUS = MISC;                        // S  : mean staging
-    static constexpr int ROT = COMPACT ? LC : (MUS + alm(S));   // 9  : rotation matrix of the mean
-    static constexpr int ZQ = COMPACT ? (MUS + alm(S)) : (ROT + alm(9));   // 12 : z (3) + Q (9)
+    static constexpr int ROT = MUS + alm(S);                // 9  : rotation matrix of the mean
+    static constexpr int ZQ = ROT + alm(9);                 // 12 : z (3) + Q (9)
     static constexpr int NSH = ZQ + 12;                     // 21 : shaped process noise of the nonlinear block
     // SINK_IN_NSH: the store sink IS the shaped-noise table.  Safe because while that table is live (from its fill to the last
     // fetch of one of its entries) every sink store is a single scalar and goes to the table's spare slot NSH_SINK; all other
     // sink stores (up to S scalars from the sink's base) happen while the table is dead.
-    static constexpr bool SINK_IN_NSH = COMPACT || ORIENT64_TRIM;
+    static constexpr bool SINK_IN_NSH = ORIENT64_TRIM;
     static constexpr int NSH_SINK = SINK_IN_NSH ? (NSH + 21) : (NSH + alm(21));   // where stores inside the table's live window send their idle lanes
     static constexpr int DUM = SINK_IN_NSH ? NSH : (NSH + alm(21));   // S  : sink for lane-predicated stores (longest: a mean / a covariance row)
     static constexpr int PF_RAW = SINK_IN_NSH ? (NSH + alm(21)) : (DUM + alm(S));
     static_assert(!SINK_IN_NSH || (alm(21) > 21 && alm(21) >= S), "the sink fits the noise table, which has a spare slot");
-    static_assert(!COMPACT || 10 <= TNL, "compact layout: the rotation matrix fits the head of the factor region");
     // LDS index (from the slice base) of covariance entry (r, c), c <= r
-    __host__ __device__ static constexpr int cv(int r, int c) {
-        if (!COMPACT) return PKS + r * (r + 1) / 2 + c;
-        return (r < NL) ? (REST + r * (r + 1) / 2 + c)
-                        : ((c < NL) ? (REST + NTRI + (r - NL) * NL + c) : (AFF + (r - NL) * (r - NL + 1) / 2 + (c - NL)));
-    }
+    __host__ __device__ static constexpr int cv(int r, int c) { return PKS + r * (r + 1) / 2 + c; }
     // Workgroups per CU follow the LDS allocation granule of 1280 B (measured, tools/lds_granule.hip; the occupancy API
     // assumes 512 B): the fp64 Pose slice must stay <= 12800 B per workgroup for 12 workgroups = 3 wavefronts per SIMD
     // (it was 13120 B = 11 workgroups per CU until round 2).
@@ -349,11 +311,9 @@ template <class T, class M> struct CovTab {
     static constexpr int RD_PR = 0, RD_PC = 1, RD_WS = 2, RD_NZ = 4, RD_ANZ = 5;   // rd row (RD_WS: one or two dwords)
     static constexpr int WR_TILE = 0, WR_AFF = TR * TC, WR_AFF_RD = TR * TC + AEL;  // wr row
     static_assert(RD_ANZ + AEL <= NRD && WR_AFF_RD + AEL <= NWR, "covariance lane tables");
-    static constexpr int EPLT = (LY::PK + 15) / 16;
     struct Tabs {
         uint32_t rd[16][NRD];
         uint32_t wr[17][NWR];
-        uint32_t stage[16][EPLT];   // LDS byte offset of packed entry l + 16 t (entries past the triangle: the sink)
     };
     static constexpr int tri_r(int e) {
         int r = 0;
@@ -395,12 +355,6 @@ template <class T, class M> struct CovTab {
                 t.wr[l][WR_AFF_RD + k] = uint32_t(LY::cv(ar, ac) * SZ);
             }
         }
-        for (int l = 0; l < 16; ++l)
-            for (int k = 0; k < EPLT; ++k) {
-                const int e = l + 16 * k;
-                const int r = tri_r(e), c = e - r * (r + 1) / 2;
-                t.stage[l][k] = (e < LY::PK) ? uint32_t(LY::cv(r, c) * SZ) : sink;
-            }
         for (int k = 0; k < NWR; ++k) t.wr[16][k] = sink;
         for (int k = 0; k < AEL; ++k) t.wr[16][WR_AFF_RD + k] = uint32_t(LY::cv(NL, NL) * SZ);
         return t;
@@ -422,17 +376,18 @@ UKFB_DEV void sfence() { __builtin_amdgcn_sched_barrier(0); }
 // not queue behind the throughput-bound phases of its SIMD neighbours.
 // Measured (same-box A/B, 300 steps): priority 1 inside the two factorisations +0.8 % fp64, +2.5..3 % fp32; raising the mean
 // iteration or the whole update as well brought nothing more.
-#ifndef UKFB_CHOL_PRIO
-#define UKFB_CHOL_PRIO 1
-#endif
-#define UKFB_PRIO(p)                                            \
-    do {                                                        \
-        if constexpr (UKFB_CHOL_PRIO != 0) __builtin_amdgcn_s_setprio(p); \
-    } while (0)
-// Phase markers (diagnostic builds only; the product build defines neither macro and they vanish):
+#define UKFB_PRIO(p) __builtin_amdgcn_s_setprio(p)
+// Phase markers (diagnostic builds only; the product build defines none of these macros and they vanish):
 //   -DUKFB_PHASE_MARKS  an assembly comment between two scheduling barriers, read by tools/isa_phases.py
-//   -DUKFB_STAMPS       lane 0 stores s_memtime to KArgs::stamps[workgroup][marker] (tools/phase_stamps.sh:
+//   -DUKFB_STAMPS       lane 0 stores s_memtime to KArgs::stamps[workgroup][marker] (tools/phase_stamps.py:
 //                       time per phase of a wavefront's life, the dynamic counterpart of the static listing)
+//   -DUKFB_COUNTS       lane 0 stores value + 1 to KArgs::stamps[workgroup][slot] (tools/trip_counts.py: trip counts of the
+//                       manifold-mean iteration per wavefront, which path the final deltas took)
+#if defined(UKFB_COUNTS)
+#define UKFB_COUNT_VAL(slot, v) do { if (threadIdx.x == 0) a.stamps[size_t(blockIdx.x) * UKFB_MAX_STAMPS + (slot)] = (unsigned long long)(v) + 1ull; } while (0)
+#else
+#define UKFB_COUNT_VAL(slot, v) do { } while (0)
+#endif
 #if defined(UKFB_STAMPS)
 enum { UKFB_STAMP_BASE = __COUNTER__ };
 #define UKFB_MARK(name)                                                                                          \
@@ -504,20 +459,6 @@ template <class T, int D> UKFB_DEV void load_row(const T* PKS, int l, T (&row)[D
     for (int j = 0; j < D; ++j) row[j] = p[j];
 }
 
-// The same from the compact slice (Layout16::COMPACT): columns < NL of row l come from the nonlinear triangle or the cross
-// block, columns >= NL from the affine triangle -- two base addresses, immediate offsets.  What lies beyond the diagonal is
-// again whatever follows (staged covariance entries, finite).
-template <class T, class LY> UKFB_DEV void load_row_compact(const T* base, int l, T (&row)[LY::D]) {
-    constexpr int D = LY::D, NL = LY::NL;
-    const int lr = (l < D) ? l : (D - 1);
-    const int la = (lr < NL) ? 0 : (lr - NL);
-    const T* pa = base + ((lr < NL) ? (LY::REST + lr * (lr + 1) / 2) : (LY::REST + LY::NTRI + la * NL));
-    const T* pb = base + LY::AFF + la * (la + 1) / 2;
-    static_assert((NL - 1) * NL / 2 + NL - 1 < LY::NREST && (D - NL - 1) * (D - NL) / 2 + D - NL - 1 < LY::NAFF, "row reads stay inside the staging");
-#pragma unroll
-    for (int j = 0; j < D; ++j) row[j] = (j < NL) ? pa[j] : pb[j - NL];
-}
-
 // scaled column l of the factor (the stored column already has zeros above the diagonal);
 // lanes without a column (l >= D) get zeros through w = 0
 template <class T, int D, int LS> UKFB_DEV void load_column(const T* Lc, int l, T rs, T (&col)[D]) {
@@ -580,14 +521,13 @@ template <class T> UKFB_DEV void process_fast(OrientM<T>*, T (&x)[14], const Pro
 }
 
 // sigma pair mu [+] (+col), mu [+] (-col): one exp serves both points, exp(-v) = conj(exp(v))
-// (QUAT_ONLY_MINUS: the Euclidean components of the minus point are left for the caller to form later)
-template <class T, class M, bool QUAT_ONLY_MINUS = false>
+template <class T, class M>
 UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], T (&xp)[M::S], T (&xm)[M::S]) {
     constexpr int Q = MT<M>::Q, RT = MT<M>::RT, S = M::S;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        if (s < Q) { xp[s] = mu[s] + col[s]; if constexpr (!QUAT_ONLY_MINUS) xm[s] = mu[s] - col[s]; }
-        else if (s >= Q + 4) { xp[s] = mu[s] + col[s - 1]; if constexpr (!QUAT_ONLY_MINUS) xm[s] = mu[s] - col[s - 1]; }
+        if (s < Q) { xp[s] = mu[s] + col[s]; xm[s] = mu[s] - col[s]; }
+        else if (s >= Q + 4) { xp[s] = mu[s] + col[s - 1]; xm[s] = mu[s] - col[s - 1]; }
     }
     const T q[4] = {mu[Q], mu[Q + 1], mu[Q + 2], mu[Q + 3]};
     const T v[3] = {col[RT], col[RT + 1], col[RT + 2]};
@@ -662,48 +602,21 @@ constexpr unsigned long long tri_cols(int first) {
     return t;
 }
 
-// minimum waves per SIMD for the register allocator (LDS admits 3 in fp64, 6 in fp32)
-// fp64 first mean iteration: 1 = transpose the NL sums through LDS, 0 = quad sums + broadcast FMAs in registers
-// (same-box A/B: 908 vs 902 M filter-cycles/s for Pose, 582 vs 585 for Orient -- a wash; the transposition stays)
-// scheduling fence between the process models of the + and - sigma point (1: the two run one after the other; 0: the
-// scheduler may interleave the two independent chains)
-#ifndef UKFB_SF_PROC
-#define UKFB_SF_PROC 1
-#endif
-#ifndef UKFB_LATE_XM
-#define UKFB_LATE_XM 0
-#endif
-#ifndef UKFB_MEAN1_TRANSPOSE
-#define UKFB_MEAN1_TRANSPOSE 1
-#endif
-#ifndef UKFB_W64
-#define UKFB_W64 2
-#endif
-#ifndef UKFB_W32
-#define UKFB_W32 5
-#endif
-template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? UKFB_W64 : UKFB_W32; }
-// wavefronts per SIMD the register allocator must leave room for, per instantiation.  The fp64 Pose kernels on the compact
-// slice fit FOUR (128 VGPRs, no spill: tools/check_resources.py) -- except the multi-cycle kernel, whose input prefetch
-// keeps it at three.
+// minimum waves per SIMD the register allocator must leave room for (LDS admits 3 in fp64, 6 in fp32), per instantiation
+template <class T> constexpr int min_waves16() { return sizeof(T) == 8 ? 2 : 5; }
 template <class T, class M, bool MULTI> constexpr int waves16() {
     if (sizeof(T) == 4) return MULTI ? 4 : min_waves16<T>();
-    if (Layout16<T, M>::COMPACT && UKFB_LATE_XM != 0) return MULTI ? 3 : 4;
     if (M::MODEL != 0 && MULTI) return 3;   // OrientationState fp64, multi-cycle: three wavefronts per SIMD (192 VGPRs = two before round 3's loop hygiene)
     return min_waves16<T>();
 }
 
 // Element idx of an array entered through a scalar base: the byte offset is formed in 32 bits, so that the load / store takes
 // the base as its scalar operand and the offset as its 32-bit vector operand (base[idx] would widen idx first and add in 64 bits)
-// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch).  With UKFB_XCD_REMAP the groups of four filters are
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch).  The groups of four filters are
 // renumbered so that every XCD works through ONE contiguous eighth of the per-filter arrays (its own pages, its own L2
 // lines) instead of every eighth group of all of them.  Scalar arithmetic; a bijection for any grid size.  Same-box A/B:
 // fp32 +0.7 % (1 M filters), +0.9 % (131 072), config 4 +1.3 %; the fp64 configurations unchanged.
-#ifndef UKFB_XCD_REMAP
-#define UKFB_XCD_REMAP 1
-#endif
 __host__ UKFB_DEV unsigned group_of_block(unsigned b, unsigned nb) {
-    if constexpr (UKFB_XCD_REMAP == 0) return b;
     const unsigned q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
     return x * q + (x < r ? x : r) + i;
 }
@@ -741,16 +654,6 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     static_assert(D + 1 <= G && S <= G, "a filter must fit one DPP row");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-#if defined(UKFB_ASSUME_HEADLINE)
-    // diagnostic build (tools/isa_phases.py --headline): the launch-uniform switches of the default bench workload become
-    // compile-time facts, so that the static listing of a phase approximates what a wavefront executes
-    __builtin_assume(a.fidx == nullptr); __builtin_assume(a.ts == nullptr); __builtin_assume(a.dt == nullptr);
-    __builtin_assume(a.meas == nullptr); __builtin_assume(a.active == nullptr); __builtin_assume(a.meas_uniform == 0);
-    __builtin_assume(a.gate_chi2 < 0); __builtin_assume(a.status_accumulate == 0);
-#define UKFB_HEADLINE_ACC(x) true
-#else
-#define UKFB_HEADLINE_ACC(x) (x)
-#endif
     if constexpr (!INDIRECT) __builtin_assume(a.fidx == nullptr);
     // Optional per-filter streams.  A multi-cycle launch has none of them BY TYPE (a compile-time null, not an assumption about
     // a kernel argument: the loads of an argument inside the cycle loop are not the load the assumption was made about, and
@@ -866,12 +769,6 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         const int e = l + G * t;
         cov_l[t] = *at(static_cast<const T*>(cov_p), fc * PK + IDX((e < PK) ? e : (PK - 1)));
     }
-    uint32_t stage_off[EPL];   // compact slice: where packed entry l + 16 t is staged (lane table, requested with the state)
-    if constexpr (LY::COMPACT) {
-        static_assert(CovTab<T, M>::EPLT == EPL, "staging table");
-#pragma unroll
-        for (int t = 0; t < EPL; ++t) stage_off[t] = CovTab<T, M>::tabs.stage[l][t];
-    }
     const T mu_l = *at(static_cast<const T*>(mu_p), fc * S + IDX((l < S) ? l : (S - 1)));
     ProcIn<T> pin;
     // per-call inputs of one input slot (single-cycle launches: slot 0 = the arrays themselves)
@@ -900,9 +797,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     int slot = MULTI ? a.cyc_first : 0;
     // fp64 (3 wavefronts per SIMD, latency-bound): a multi-cycle launch requests the inputs of the next cycle before this
     // cycle's arithmetic, into registers -- the first cycle's here, with the state (OrientationState fp64, same-box: 805 M
-    // filter-cycles/s with the prefetch, 787 M without; UKFB_PREFETCH_ORIENT64).  The fp32 multi-cycle kernels (6 per SIMD,
+    // filter-cycles/s with the prefetch, 787 M without).  The fp32 multi-cycle kernels (6 per SIMD,
     // issue-bound) load every cycle's inputs at the head of that cycle: nothing is carried around the cycle loop.
-    constexpr bool PREFETCH = MULTI && sizeof(T) == 8 && (UKFB_PREFETCH_ORIENT64 != 0 || M::MODEL == 0);
+    constexpr bool PREFETCH = MULTI && sizeof(T) == 8;
     if constexpr (MULTI) {
         if constexpr (PREFETCH) load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
     } else {
@@ -923,15 +820,10 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 
     UKFB_MARK("stage");
     // ---- stage the filter in LDS: packed covariance, mean, measurement
-    if constexpr (LY::COMPACT) {   // split staging (affine triangle | nonlinear triangle + cross block): offsets from the lane table
 #pragma unroll
-        for (int t = 0; t < EPL; ++t) *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + stage_off[t]) = cov_l[t];
-    } else {
-#pragma unroll
-        for (int t = 0; t < EPL; ++t) {
-            const int e = l + G * t;
-            PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = cov_l[t];
-        }
+    for (int t = 0; t < EPL; ++t) {
+        const int e = l + G * t;
+        PKS[(e < PK) ? e : (LY::DUM - LY::PKS)] = cov_l[t];
     }
     MUS[(l < S) ? l : (LY::DUM - LY::MUS)] = mu_l;
     const bool live = fvalid && (init_b != 0);
@@ -1058,8 +950,6 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             // stored index of a nonlinear Euclidean tangent component t (t outside [RT, RT + 3))
             constexpr auto st_of = [](int t) constexpr { return t < MT<M>::RT ? t : t + 1; };
             T xp[S], xm[S], ref[S];
-            constexpr bool LATE_XM = (sizeof(T) == 8) && (UKFB_LATE_XM != 0);
-            T rs_keep = T(0);
             bool ok;
             bool noise_plain = false;   // wave-uniform: the process noise needs no rotation (see below)
             bool need_rot = false;      // wave-uniform: the rotated noise blocks are evaluated, they need the mean's rotation matrix
@@ -1068,9 +958,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 T mu_r[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
-                // (the late-minus-point variant takes it after the process models, from the staging: two registers less at the peak)
-                if constexpr (!(LATE_XM && M::MODEL == 0))
-                    qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
+                qn2 = mu_r[Q] * mu_r[Q] + mu_r[Q + 1] * mu_r[Q + 1] + mu_r[Q + 2] * mu_r[Q + 2] + mu_r[Q + 3] * mu_r[Q + 3];
                 // rotation matrix of the current mean (PoseUKF.cpp:182 / OrientationUKF.cpp:81); the Pose acceleration branch does
                 // not rotate its noise (wave-uniform skip).  An isotropic block is its own rotation (R s I R^T = s I R R^T): with
                 // the launch-wide flag set by the host and unit orientation quaternions (|q|^2 within 1e-9 of 1 on every lane,
@@ -1079,41 +967,34 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 // (OrientationState kernels only: in the Pose kernels the two extra branches cost the acceleration-branch
                 // headline 0.6 % through code placement alone, same-box A/B)
                 if constexpr (M::MODEL != 0)
-                    noise_plain = a.noise_iso != 0 && wave_all(!do_p || m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(UKFB_ISO_TOL_F32)));
-                need_rot = !noise_plain && (M::MODEL != 0 || !UKFB_HEADLINE_ACC(wave_all(pin.use_acc)));
-                if constexpr (!LY::COMPACT) {
-                    if (need_rot) {
-                        T q[4], rot[9];
-                        M::orientation(mu_r, q);
-                        quat_to_matrix(q, rot);
-                        T* dst = (l == 0) ? ROT : DUMP;
+                    noise_plain = a.noise_iso != 0 && wave_all(!do_p || m_abs(qn2 - T(1)) <= (sizeof(T) == 8 ? T(1e-9) : T(ISO_TOL_F32)));
+                need_rot = !noise_plain && (M::MODEL != 0 || !wave_all(pin.use_acc));
+                if (need_rot) {
+                    T q[4], rot[9];
+                    M::orientation(mu_r, q);
+                    quat_to_matrix(q, rot);
+                    T* dst = (l == 0) ? ROT : DUMP;
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) dst[k] = rot[k];
-                    }
+                    for (int k = 0; k < 9; ++k) dst[k] = rot[k];
                 }
                 T rs;
                 {
                     T arow[D];
                     UKFB_MARK("p_chol_row");
-                    if constexpr (LY::COMPACT) load_row_compact<T, LY>(base, l, arow);
-                    else load_row<T, D>(PKS, l, arow);
+                    load_row<T, D>(PKS, l, arow);
                     UKFB_MARK("p_chol_fact");
-                    UKFB_PRIO(UKFB_CHOL_PRIO);
+                    UKFB_PRIO(1);
                     rs = chol16<T, D, LS>(arow, Lc, l, ok);
                     UKFB_PRIO(0);
                     wsync();
                 }
                 UKFB_MARK("p_sigma");
-                rs_keep = rs;
                 T col[D];
                 load_column<T, D, LS>(Lc, l, rs, col);
                 {   // affine rows of this lane's column, scaled by the model's diagonal factor, for the cross block;
                     // lanes without a column hold zeros: they fill LAF's zero row, or go to the sink where that row is
                     // not stored (Layout16::LAF_ROW_D)
-                    // (compact slice: LAF aliases staged covariance entries that a filter whose prediction is not committed
-                    // must keep -- its rows go to the sink, its cross lanes then read finite leftovers and store nothing)
-                    T* lrow = LY::LAF_ROW_D ? (LAF + ((l < D) ? l : D) * ST)
-                                            : (((l < D) && (!LY::COMPACT || (do_p && ok))) ? (LAF + l * ST) : DUMP);
+                    T* lrow = LY::LAF_ROW_D ? (LAF + ((l < D) ? l : D) * ST) : ((l < D) ? (LAF + l * ST) : DUMP);
 #pragma unroll
                     for (int c = NL; c < D; ++c) lrow[c - NL] = (M::MODEL == 0) ? col[c] : col[c] * MT<M>::aff_scale(c, pin);
                     if constexpr (LY::LAF_PAD > 0) {   // see Layout16::LAF_PAD
@@ -1122,42 +1003,16 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                         for (int k = 0; k < LY::LAF_PAD; ++k) padp[k] = T(0);
                     }
                 }
-                sigma_pair<T, M, LATE_XM>(mu_r, col, xp, xm);
+                sigma_pair<T, M>(mu_r, col, xp, xm);
             }
             UKFB_MARK("p_process");
             const bool pc = do_p && ok;            // this filter's predict will be committed
             sfence();
             process_fast((M*)nullptr, xp, pin);    // lanes >= D carry the centre point (their column is zero)
-            if constexpr (UKFB_SF_PROC != 0) sfence();
-            if constexpr (LATE_XM) {
-                // fp64: the Euclidean part of the minus point is formed only now, from the staged mean and the factor column
-                // (both still in LDS): thirteen values less to hold through the first process model, where the register
-                // demand of the whole kernel peaks (tools/isa_liveness.py); its quaternion came with the plus point's
-                const int lc = (l < D) ? l : (D - 1);
-                const T w = (l < D) ? rs_keep : T(0);
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (s < Q) xm[s] = fma(-Lc[lc * LS + s], w, MUS[s]);
-                    else if (s >= Q + 4) xm[s] = fma(-Lc[lc * LS + s - 1], w, MUS[s]);
-                }
-            }
-            if constexpr (LATE_XM) {
-                // ... and the affine part of the new mean, which IS the propagated centre (see p_mean1), leaves the centre
-                // lane's registers right away
-                T* dstc0 = (pc && has_ctr) ? MUS : DUMP;
-                T* dstc = dstc0;
-                asm volatile("" : "+v"(dstc));
-                // (after every lane has read the old mean for its minus point: one wavefront, LDS in program order)
-#pragma unroll
-                for (int s = NL + 1; s < S; ++s) dstc[s] = xp[s];
-            }
+            sfence();   // the two process models run one after the other (interleaved by the scheduler: same registers, no gain)
             process_fast((M*)nullptr, xm, pin);
             sfence();
             UKFB_MARK("p_mean1");
-            if constexpr (LATE_XM && M::MODEL == 0) {   // |q|^2 of the OLD mean (its quaternion is still staged)
-                const T q0 = MUS[Q], q1 = MUS[Q + 1], q2 = MUS[Q + 2], q3 = MUS[Q + 3];
-                qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
-            }
             // Propagated centre point (lane D): every lane starts the mean from it.  The affine components
             // (tangent >= NL) of the sigma points are centre +- scale * L[c][l] exactly, so their mean IS the centre
             // (ukfom's iteration finds a correction at rounding level) and their deltas are the signed factor rows.
@@ -1186,7 +1041,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 for (int t = 0; t < NL; ++t)
                     if (t < RT || t >= RT + 3) loc[t] = fma(wm, xm[st_of(t)] - ref[st_of(t)], wp * (xp[st_of(t)] - ref[st_of(t)]));
                 T md[NL];
-                if constexpr (sizeof(T) == 8 && UKFB_MEAN1_TRANSPOSE) {
+                if constexpr (sizeof(T) == 8) {
                     // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) factor region:
                     // lane c sums component c over the 16 lanes and publishes the mean
                     constexpr int TS = 18;   // row stride: b128 rows of lanes 0..NL-1 fall on distinct banks
@@ -1234,19 +1089,6 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             UKFB_MARK("p_delta_e");
             // Euclidean part of the mean is final: write those delta columns now and drop the registers.
             wsync();  // every lane is done with the transposition buffer (it aliases the table)
-            if constexpr (LY::COMPACT) {
-                // compact slice: the rotation matrix of the (old) mean goes to the head of the factor region, which nothing
-                // reads any more (columns loaded, transposition done; the table starts behind it) -- the quaternion is still
-                // the old one in the mean staging (the new one follows in p_delta_r)
-                if (need_rot) {
-                    const T q[4] = {MUS[Q], MUS[Q + 1], MUS[Q + 2], MUS[Q + 3]};
-                    T rot[9];
-                    quat_to_matrix(q, rot);
-                    T* dst = (l == 0) ? ROT : DUMP;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) dst[k] = rot[k];
-                }
-            }
             // rows 0..D (lane l <= D): U_l, the centre lane's row scaled by sqrt(1/2) (its U is delta_0);
             // rows D+1..N: W_l, where the centre lane's W = 0 is the table's zero row
             T* const rowu = has_p ? (TAB + l * ST) : DUMP;
@@ -1266,7 +1108,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 T* dstc = (pc && has_ctr) ? MUS : DUMP;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if (s >= NL + 1) { if constexpr (!LATE_XM) dstc[s] = xp[s]; }
+                    if (s >= NL + 1) dstc[s] = xp[s];
                     else if (s < Q || s >= Q + 4) dst[s] = ref[s];
                 }
             }
@@ -1285,7 +1127,13 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 bool active = pc && n2 > a.mean_tol * a.mean_tol;   // (rows that commit nothing never keep the wavefront iterating)
                 int it = 0;
                 if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
+#if defined(UKFB_COUNTS)
+                int wave_trips = 0;
+#endif
                 while (wave_any(active)) {
+#if defined(UKFB_COUNTS)
+                    ++wave_trips;
+#endif
                     T rp[3], rm[3], mr[3];
                     rot_minus_n(qp, qr, qn2, rp);
                     rot_minus_n(qm, qr, qn2, rm);
@@ -1316,6 +1164,10 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     conv = conv && !(active && capped);
                     active = active && more && !capped;
                 }
+#if defined(UKFB_COUNTS)
+                UKFB_COUNT_VAL(0, wave_trips);                      // trips of the wavefront (max over its four filters)
+                UKFB_COUNT_VAL(1, it);                              // iterations of row 0's filter (incl. the first, p_mean1)
+#endif
             }
             UKFB_MARK("p_delta_r");
             // lane constants of the covariance phase (CovTab, Pose kernels), requested here so that they have arrived when it starts
@@ -1338,6 +1190,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     // has no say in what its wave-mates do)
                     rebase = wave_all(!pc || (tp <= T(2.25) && tm <= T(2.25) && a2 <= T(1e-12)));
                 }
+                UKFB_COUNT_VAL(2, rebase ? 1 : 0);                  // final deltas: re-based (1) or a third round of logarithms (0)
                 if (rebase) {
                     so3_rebase_small(rpl, al, a2, rp);
                     so3_rebase_small(rml, al, a2, rm);
@@ -1395,7 +1248,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     const T rn = at_off(Rn, off, imm), vacc = at_off(Ra, off, imm);
                     return pin.use_acc ? vacc : pin.dt * rn;
                 };
-                const bool all_acc = UKFB_HEADLINE_ACC(wave_all(pin.use_acc));
+                const bool all_acc = wave_all(pin.use_acc);
                 // shaped process noise of this lane's tile: requested before the accumulation loop, consumed after it
                 T acc[TR][TC], nz[TR][TC], anz[AEL];
 #pragma unroll
@@ -1489,7 +1342,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 const int64_t wgn = wg0_again() * a.Rn_stride;
                 const T* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
                 const T* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
-                const bool all_acc = NZ_EARLY && UKFB_HEADLINE_ACC(wave_all(pin.use_acc));
+                const bool all_acc = NZ_EARLY && wave_all(pin.use_acc);
                 // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
                 // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
                 int ar[AEL], ac[AEL];
@@ -1744,12 +1597,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 T rs;
                 {
                     T arow[D];
-                    if constexpr (LY::COMPACT) load_row_compact<T, LY>(base, l, arow);
-                    else load_row<T, D>(PKS, l, arow);
+                    load_row<T, D>(PKS, l, arow);
                     // Only the first ZCOLS columns of the factor move the measurement.  An indefinite Sigma whose
                     // first ZCOLS pivots are positive is caught by the complete factorisation of Sigma' below
                     // (Sigma' <= Sigma), with the same status bit.
-                    UKFB_PRIO(UKFB_CHOL_PRIO);
+                    UKFB_PRIO(1);
                     rs = chol16<T, D, LS, MT<M>::ZCOLS>(arow, Lc, l, okg);
                     UKFB_PRIO(0);
                     wsync();
@@ -1920,8 +1772,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             T rs2;
             {
                 T arow2[D];
-                if constexpr (LY::COMPACT) load_row_compact<T, LY>(base, l, arow2);
-                else load_row<T, D>(PKS, l, arow2);
+                load_row<T, D>(PKS, l, arow2);
                 const T nks[3] = {-KSr[0], -KSr[1], -KSr[2]};
                 dpp_hazard_fence(Kr[0]);
                 dpp_hazard_fence(Kr[1]);
@@ -1934,7 +1785,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     srow2[b] = arow2[b];
                     d0[b] = row_bcast<b>(del);
                 });
-                UKFB_PRIO(UKFB_CHOL_PRIO);
+                UKFB_PRIO(1);
                 rs2 = chol16<T, D, LS, D, RT + 3>(arow2, Lc, l, ok2);   // applyDelta reads the first RT + 3 columns only
                 UKFB_PRIO(0);
                 wsync();
@@ -2013,31 +1864,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 // rowbase(l)) > c, i.e. earlier in this descending loop.  The last row has nothing beyond its diagonal.
                 // (The stores of one lane never alias each other, so the compiler would be free to reorder or pair
                 // them; the order that matters is between LANES, hence the compiler fence after every store.)
-                if constexpr (LY::COMPACT) {
-                    // The compact slice keeps two triangles (nonlinear rows / columns < NL; affine >= NL) and the cross block
-                    // apart.  The argument above holds inside each triangle with its local column index; the cross rows
-                    // have no entry beyond a diagonal at all.  Columns < NL first, then columns >= NL (rows < NL: the sink).
-                    constexpr int NL = LY::NL;
-                    const int la = (l < NL) ? 0 : (l - NL);
-                    T* dsta = wl ? (base + ((l < NL) ? (LY::REST + l * (l + 1) / 2) : (LY::REST + LY::NTRI + la * NL))) : DUMP;
-                    T* dstb = (wl && l >= NL) ? (base + LY::AFF + la * (la + 1) / 2) : DUMP;
+                T* rowdst = wl ? (PKS + l * (l + 1) / 2) : DUMP;
 #pragma unroll
-                    for (int b = NL - 1; b >= 0; --b) {
-                        dsta[b] = srow2[b];
-                        asm volatile("" ::: "memory");
-                    }
-#pragma unroll
-                    for (int b = D - 1; b >= NL; --b) {
-                        dstb[b - NL] = srow2[b];
-                        asm volatile("" ::: "memory");
-                    }
-                } else {
-                    T* rowdst = wl ? (PKS + l * (l + 1) / 2) : DUMP;
-#pragma unroll
-                    for (int b = D - 1; b >= 0; --b) {
-                        rowdst[b] = srow2[b];
-                        asm volatile("" ::: "memory");
-                    }
+                for (int b = D - 1; b >= 0; --b) {
+                    rowdst[b] = srow2[b];
+                    asm volatile("" ::: "memory");
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -2105,12 +1936,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const int e = l + G * t;
-            if constexpr (LY::COMPACT) {
-                const uint32_t off = CovTab<T, M>::tabs.stage[l][t];
-                if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = *reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base) + off);
-            } else {
-                if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = PKS[e];
-            }
+            if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = PKS[e];
         }
         if (l < S) *at(mu_c, fcc * S + IDX(l)) = MUS[l];
     }

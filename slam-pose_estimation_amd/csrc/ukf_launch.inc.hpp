@@ -37,11 +37,11 @@ template <class T, class M, int G> static int launch_g(ukfb_engine* e, const Lau
     return UKFB_OK;
 }
 
-#ifdef UKFB_STAMPS
-// Diagnostic build (tools/phase_stamps.sh): every launch is synchronous; the per-marker s_memtime stamps of
+#if defined(UKFB_STAMPS) || defined(UKFB_COUNTS)
+// Diagnostic builds (tools/phase_stamps.py, tools/trip_counts.py): every launch is synchronous; the per-marker s_memtime stamps of
 // all wavefronts are reduced to mean cycles between consecutive executed markers and appended to the file
 // named by UKFB_STAMP_OUT (one line per launch: kernel name, then marker_index:mean_delta pairs).
-template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds) {
+template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds, bool plain) {
     static unsigned long long* dbuf = nullptr;
     static size_t dcap = 0;
     const size_t need = size_t(grid) * UKFB_MAX_STAMPS;
@@ -53,10 +53,20 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
     (void)hipMemsetAsync(dbuf, 0, need * 8, main_stream(e));
     args.stamps = dbuf;
     const dim3 gd((unsigned)grid), bd(64);
+#if defined(UKFB_COUNTS)
+    {
+        unsigned long long zero[DBG_N] = {0};
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(ukfb_dbg), zero, sizeof(zero), 0, hipMemcpyHostToDevice, main_stream(e));
+    }
+#endif
     if (args.fidx)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
+    else if (r.cycles > 0 && plain)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true, false, true>), gd, bd, lds, main_stream(e), args);
     else if (r.cycles > 0)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
+    else if (plain)
+        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, false, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict && r.do_update)
         hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)
@@ -68,6 +78,34 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
     if (!path) return UKFB_OK;
     std::vector<unsigned long long> h(need);
     if (hipMemcpy(h.data(), dbuf, need * 8, hipMemcpyDeviceToHost) != hipSuccess) return UKFB_ERR_HIP;
+#if defined(UKFB_COUNTS)
+    {   // histogram of every counter slot over the wavefronts of the launch, then the exp / log path counters
+        unsigned long long dbg[DBG_N] = {0};
+        if (hipMemcpyFromSymbol(dbg, HIP_SYMBOL(ukfb_dbg), sizeof(dbg)) != hipSuccess) return UKFB_ERR_HIP;
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "%s grid=%lld", e->last_kernel.c_str(), (long long)grid);
+            for (int k = 0; k < 4; ++k) {
+                int64_t hist[18] = {0};
+                bool any = false;
+                for (int64_t w = 0; w < grid; ++w) {
+                    const unsigned long long v = h[size_t(w) * UKFB_MAX_STAMPS + k];
+                    if (!v) continue;
+                    any = true;
+                    ++hist[(v - 1) < 17 ? (v - 1) : 17];
+                }
+                if (!any) continue;
+                fprintf(f, " slot%d=", k);
+                for (int b = 0; b < 18; ++b)
+                    if (hist[b]) fprintf(f, "%d:%lld,", b, (long long)hist[b]);
+            }
+            fprintf(f, " dbg=");
+            for (int k = 0; k < DBG_N; ++k) fprintf(f, "%llu,", dbg[k]);
+            fprintf(f, "\n");
+            fclose(f);
+        }
+        return UKFB_OK;
+    }
+#endif
     double sum[UKFB_MAX_STAMPS] = {0};
     int64_t cnt[UKFB_MAX_STAMPS] = {0};
     double life = 0;
@@ -128,8 +166,8 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     e->last_grid = grid;
     if (grid == 0) return UKFB_OK;
     const dim3 gd((unsigned)grid), bd(64);
-#ifdef UKFB_STAMPS
-    return launch_row16_stamped<T, M>(e, r, args, grid, lds);
+#if defined(UKFB_STAMPS) || defined(UKFB_COUNTS)
+    return launch_row16_stamped<T, M>(e, r, args, grid, lds, plain);
 #endif
     // Two half launches on two streams (engines that own their stream, direct launches of SPLIT_MIN <= n < SPLIT_MAX filters):
     // launch k + 1's first half follows launch k's first half on `stream`, its second half follows launch k's second half on

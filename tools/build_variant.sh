@@ -2,11 +2,24 @@
 # Builds an experimental engine variant next to the product library (never committed, not gated):
 #   tools/build_variant.sh <name> [extra hipcc flags...]  ->  slam-pose_estimation_amd/lib/ab/<name>.so
 # Used with tools/ab.sh for same-box A/B timing.  Same flags as csrc/Makefile (MachineLICM off for the kernel TUs only).
-# e.g. the rejected four-wavefront variant of round 3:  tools/build_variant.sh compact64 -DUKFB_COMPACT64=1 -DUKFB_LATE_XM=1
+#   tools/build_variant.sh <name> --patch tools/variants/X.patch [flags...]  builds from a scratch copy of csrc/ with the patch
+#   applied (`patch -p1` from the repo root's point of view): measured-and-rejected variants live as patches, not as
+#   switches in the product headers.  e.g. the rejected four-wavefront variant of round 3:
+#   tools/build_variant.sh compact64 --patch tools/variants/r03_rejected_switches.patch -DUKFB_COMPACT64=1 -DUKFB_LATE_XM=1
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/slam-pose_estimation_amd/csrc
+if [ "$1" = "--patch" ]; then
+  pf=$(cd "$(dirname "$2")" && pwd)/$(basename "$2"); shift 2
+  scratch=$(mktemp -d)
+  trap 'rm -rf "$scratch"' EXIT
+  mkdir -p $scratch/slam-pose_estimation_amd $scratch/include
+  cp -r $src $scratch/slam-pose_estimation_amd/csrc
+  cp -r $root/include/. $scratch/include/
+  (cd $scratch && patch -s -p1 < "$pf")
+  src=$scratch/slam-pose_estimation_amd/csrc
+fi
 out=$root/slam-pose_estimation_amd/lib/ab
 obj=$out/obj_$name
 mkdir -p $obj

@@ -4,7 +4,13 @@ mean shader cycles between consecutive phase markers of ukf_kernel16 (s_memtime,
 i.e. where a wavefront's life goes, at several points of the bench trajectory (the orientation spread of the
 headline workload grows with the cycle count, which moves the SO(3) log onto its half-angle path).
 
-usage: UKFB_LIB=slam-pose_estimation_amd/lib/ab/stamps.so python3 tools/phase_stamps.py [pose|orient|pose-mixed] [f64|f32] [filters]"""
+usage: UKFB_LIB=slam-pose_estimation_amd/lib/ab/stamps.so python3 tools/phase_stamps.py [pose|orient|pose-mixed] [f64|f32] [filters]
+
+With a -DUKFB_COUNTS build and --counts as LAST argument (tools/build_variant.sh counts -DUKFB_COUNTS): per launch, the histogram over
+wavefronts of the manifold-mean trip counts (slot0: wave trips of the iteration loop = max over the wavefront's four filters;
+slot1: iterations of one filter incl. the first; slot2: final deltas re-based (1) or by a third round of logarithms (0)) and how
+many of the wavefront-level exp / log calls took their wide-angle paths (dbg = exp calls, exp angle-doubling, exp mod-2pi,
+log_n calls, log_n half-angle path, log calls, log half-angle path)."""
 import torch  # noqa: F401
 import os
 import re
@@ -15,6 +21,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import slam_pose_estimation_amd as spe  # noqa: E402
 
+COUNTS = sys.argv[-1] == "--counts"
+if COUNTS:
+    sys.argv.pop()
 workload = sys.argv[1] if len(sys.argv) > 1 else "pose"
 prec = spe.F64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else spe.F32
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
@@ -69,7 +78,7 @@ def step(k):
         e.cycle_dev(0.01, spe.MEAS_POS3, b["z"], b["Q"], meas_model_dev=b["m"] if workload == "pose-mixed" else None)
 
 
-report_at = [3, 60, 150, 300, 600]
+report_at = [0, 1, 3, 10, 30, 60, 100, 150, 200, 300, 400, 500, 600] if COUNTS else [3, 60, 150, 300, 600]
 k = 0
 for target in report_at:
     os.environ.pop("UKFB_STAMP_OUT", None)
@@ -80,6 +89,11 @@ for target in report_at:
 os.environ.pop("UKFB_STAMP_OUT", None)
 print("status_or", e.status_summary())
 lines = open(out).read().strip().splitlines()
+if COUNTS:
+    print(f"{workload} {'f64' if prec == spe.F64 else 'f32'} n={n}: per-wavefront counters of the launch at cycle index")
+    for cyc, line in zip(report_at, lines):
+        print(f"@{cyc:4d} {line}")
+    sys.exit(0)
 print(f"{workload} {'f64' if prec == spe.F64 else 'f32'} n={n}: mean cycles between markers (s_memtime), per launch at cycle index")
 table = {}
 for cyc, line in zip(report_at, lines):

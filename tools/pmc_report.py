@@ -32,7 +32,7 @@ def kernel_ns(d, kernel_substr):
     return sum(vals) / len(vals) if vals else None
 
 
-# DPP-fused fp32 arithmetic on the default path of each kernel (static listing, tools/isa_phases.py -DUKFB_ASSUME_HEADLINE):
+# DPP-fused fp32 arithmetic on the default path of each kernel (static listing, tools/isa_phases.py ):
 # the SQ counts them as FMA / ADD, the SIMD issues them at the 4-cycle rate
 DPP_FUSED_F32 = {"ukf_kernel16<f32,pose,cycle>": 243.0, "ukf_kernel16<f32,orient,cycle>": 300.0,
                  # (the plain-launch instantiations run the same factorisations)

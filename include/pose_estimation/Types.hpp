@@ -37,6 +37,7 @@ template <typename Scalar, int R, int C> using Matrix = Eigen::Matrix<Scalar, R,
 typedef Eigen::Vector3d Vector3d;
 typedef Eigen::Matrix3d Matrix3d;
 typedef Eigen::Quaterniond Quaterniond;
+template <typename M, typename Scalar, int BR, int BC> using FixedBlock = Eigen::Block<M, BR, BC>;   // (xpr, startRow, startCol)
 }  // namespace pose_estimation
 
 #else
@@ -74,6 +75,18 @@ public:
 private:
     M& m_;
     int r0_, c0_, h_, w_;
+};
+
+// The same with the size known at compile time: what Eigen's block<BR, BC>(r, c) returns (and MTK::subblock).  It takes part in
+// products like a BR x BC matrix.
+template <typename M, typename Scalar, int BR, int BC> class FixedBlock : public BlockView<M, Scalar> {
+public:
+    FixedBlock(M& m, int r0, int c0) : BlockView<M, Scalar>(m, r0, c0, BR, BC) {}
+    using BlockView<M, Scalar>::operator=;
+    FixedBlock& operator=(const FixedBlock& b) { BlockView<M, Scalar>::operator=(b); return *this; }
+    Matrix<Scalar, BR, BC> eval() const { return Matrix<Scalar, BR, BC>(*this); }
+    template <int K> Matrix<Scalar, BR, K> operator*(const Matrix<Scalar, BC, K>& o) const { return eval() * o; }
+    Matrix<Scalar, BC, BR> transpose() const { return eval().transpose(); }
 };
 
 template <typename Scalar, int R, int C> struct Matrix {
@@ -141,8 +154,9 @@ template <typename Scalar, int R, int C> struct Matrix {
     // Eigen's two block forms: run-time size (a view) and compile-time size (also a view)
     BlockView<Matrix, Scalar> block(int r0, int c0, int h, int w) { return BlockView<Matrix, Scalar>(*this, r0, c0, h, w); }
     BlockView<const Matrix, Scalar> block(int r0, int c0, int h, int w) const { return BlockView<const Matrix, Scalar>(*this, r0, c0, h, w); }
-    template <int BR, int BC> BlockView<Matrix, Scalar> block(int r0, int c0) { return BlockView<Matrix, Scalar>(*this, r0, c0, BR, BC); }
-    template <int BR, int BC> BlockView<const Matrix, Scalar> block(int r0, int c0) const { return BlockView<const Matrix, Scalar>(*this, r0, c0, BR, BC); }
+    template <int BR, int BC> FixedBlock<Matrix, Scalar, BR, BC> block(int r0, int c0) { return FixedBlock<Matrix, Scalar, BR, BC>(*this, r0, c0); }
+    template <int BR, int BC> FixedBlock<const Matrix, Scalar, BR, BC> block(int r0, int c0) const { return FixedBlock<const Matrix, Scalar, BR, BC>(*this, r0, c0); }
+    template <typename M2, int K> Matrix<Scalar, R, K> operator*(const FixedBlock<M2, Scalar, C, K>& b) const { return *this * b.eval(); }
     BlockView<Matrix, Scalar> topLeftCorner(int h, int w) { return block(0, 0, h, w); }
     BlockView<Matrix, Scalar> row(int r) { return block(r, 0, 1, C); }
     BlockView<Matrix, Scalar> col(int c) { return block(0, c, R, 1); }
@@ -226,15 +240,7 @@ template <typename Scalar, int R, int C> inline void from_row_major(const double
 }
 }  // namespace pose_estimation
 
-// MTK::SO3<double>(q): the wrapper type the reference converts an Eigen quaternion through
-// (src/pose_with_velocity/BodyStateMeasurement.hpp:17).  With real MTK installed this header is not the one in use.
-#if !(defined(__has_include) && __has_include(<mtk/types/SOn.hpp>))
-namespace MTK {
-template <typename Scalar> struct SO3 : pose_estimation::Quaterniond {
-    SO3() {}
-    SO3(const pose_estimation::Quaterniond& q) : pose_estimation::Quaterniond(q) {}
-};
-}  // namespace MTK
-#endif
+// the MTK / ukfom value types the reference's public headers name (MTK::SO3, MTK::vect, ukfom::mtkwrap, ukfom::ukf<>::cov)
+#include <pose_estimation/Manifold.hpp>
 
 #endif

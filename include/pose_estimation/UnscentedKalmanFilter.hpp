@@ -28,8 +28,9 @@ public:
         DOF = Manifold::DOF
     };
     typedef Manifold State;
-    typedef Manifold WState;
-    typedef Matrix<double, int(Manifold::DOF), int(Manifold::DOF)> Covariance;
+    typedef ukfom::mtkwrap<Manifold> WState;       // :23  (value type with operator+ / operator-, pose_estimation/Manifold.hpp)
+    typedef ukfom::ukf<WState> MTK_UKF;            // :24  (the type names cov / scalar_type / state; the arithmetic is the engine's)
+    typedef typename MTK_UKF::cov Covariance;      // :25
 
     UnscentedKalmanFilter() : engine(NULL), initialised(false)
     {
@@ -40,6 +41,9 @@ public:
         int rc = ukfb_create(&engine, Manifold::ENGINE_MODEL, UKFB_F64, 1, 0, NULL);
         if (rc != UKFB_OK)
             throw std::runtime_error(std::string("pose_estimation: MI355X engine unavailable: ") + ukfb_last_error());
+        ukfb_get_config(engine, &engine_cfg);
+        pushed_min_time_delta = engine_cfg.min_time_delta;
+        pushed_max_time_delta = engine_cfg.max_time_delta;
     }
 
     virtual ~UnscentedKalmanFilter() { ukfb_destroy(engine); }
@@ -151,11 +155,14 @@ protected:
     /** One engine predict with the host-side gate already passed (the engine re-checks with the same bounds). */
     void enginePredict(double delta_t)
     {
-        ukfb_config cfg;
-        ukfb_get_config(engine, &cfg);
-        cfg.min_time_delta = min_time_delta;
-        cfg.max_time_delta = max_time_delta;
-        ukfb_set_config(engine, &cfg);
+        // the engine's own copy of the two bounds follows the accessors; it is pushed only when one of them changed
+        if (min_time_delta != pushed_min_time_delta || max_time_delta != pushed_max_time_delta) {
+            engine_cfg.min_time_delta = min_time_delta;
+            engine_cfg.max_time_delta = max_time_delta;
+            check(ukfb_set_config(engine, &engine_cfg), "set_config");
+            pushed_min_time_delta = min_time_delta;
+            pushed_max_time_delta = max_time_delta;
+        }
         check(ukfb_predict(engine, delta_t), "predict");
         check(ukfb_sync(engine), "sync");
     }
@@ -185,6 +192,8 @@ private:
 
 protected:
     ukfb_engine* engine;              // replaces boost::shared_ptr<MTK_UKF> ukf (:150)
+    ukfb_config engine_cfg;           // the engine's configuration as created (+ the two time bounds last pushed)
+    double pushed_min_time_delta, pushed_max_time_delta;
     bool initialised;
     Covariance process_noise_cov;
     base::Time last_measurement_time;

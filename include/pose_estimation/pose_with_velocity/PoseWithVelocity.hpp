@@ -1,7 +1,9 @@
 // pose_estimation/pose_with_velocity/PoseWithVelocity.hpp -- host mirror of the 12-DOF manifold
 // (reference: src/pose_with_velocity/PoseWithVelocity.hpp:14-25): position (vect3), orientation (SO3),
-// velocity (vect3), angular_velocity (vect3), in that order.  Values only; boxplus / boxminus live in
-// the engine (slam-pose_estimation_amd/csrc/ukf_device.hpp).
+// velocity (vect3), angular_velocity (vect3), in that order, with the reference's type names
+// (ukfom::mtkwrap< MTK::SO3<double> > RotationType, ...).  boxplus / boxminus here are single-value caller
+// conveniences (pose_estimation/Manifold.hpp); the filters' own [+] / [-] run in the engine
+// (slam-pose_estimation_amd/csrc/ukf_device.hpp).
 #ifndef _POSE_WITH_VELOCITY_HPP_
 #define _POSE_WITH_VELOCITY_HPP_
 
@@ -11,19 +13,44 @@
 namespace pose_estimation
 {
 
-typedef Quaterniond RotationType;
-typedef Vector3d TranslationType;
-typedef Vector3d VelocityType;
+typedef ukfom::mtkwrap< MTK::SO3<double> > RotationType;
+typedef ukfom::mtkwrap<RotationType::vect_type> TranslationType;
+typedef ukfom::mtkwrap<RotationType::vect_type> VelocityType;
 
+// (MTK_BUILD_MANIFOLD in the reference: DOF, scalar, field-wise boxplus / boxminus in declaration order)
 struct PoseWithVelocity
 {
     enum { DOF = 12, STORED = 13, ENGINE_MODEL = UKFB_MODEL_POSE };
     typedef double scalar;
+    typedef Matrix<double, 12, 1> vectorized_type;
 
     TranslationType position;
     RotationType orientation;
     VelocityType velocity;
     VelocityType angular_velocity;
+
+    /** tangent offset of a field named by its member pointer (MTK::subblock / MTK::setDiagonal) */
+    static int tangentIndex(TranslationType PoseWithVelocity::*f)
+    {
+        return f == &PoseWithVelocity::position ? 0 : (f == &PoseWithVelocity::velocity ? 6 : 9);
+    }
+    static int tangentIndex(RotationType PoseWithVelocity::*) { return 3; }
+
+    void boxplus(const vectorized_type& d, scalar scale = 1.0)
+    {
+        position.boxplus(Vector3d(d[0], d[1], d[2]), scale);
+        orientation.boxplus(Vector3d(d[3], d[4], d[5]), scale);
+        velocity.boxplus(Vector3d(d[6], d[7], d[8]), scale);
+        angular_velocity.boxplus(Vector3d(d[9], d[10], d[11]), scale);
+    }
+    void boxminus(vectorized_type& res, const PoseWithVelocity& other) const
+    {
+        Vector3d t;
+        position.boxminus(t, other.position);                 res[0] = t[0]; res[1] = t[1]; res[2] = t[2];
+        orientation.boxminus(t, other.orientation);           res[3] = t[0]; res[4] = t[1]; res[5] = t[2];
+        velocity.boxminus(t, other.velocity);                 res[6] = t[0]; res[7] = t[1]; res[8] = t[2];
+        angular_velocity.boxminus(t, other.angular_velocity); res[9] = t[0]; res[10] = t[1]; res[11] = t[2];
+    }
 
     // engine layout: p(3) q(x,y,z,w) v(3) w(3)   (include/ukf_batch.h)
     void toArray(double* a) const

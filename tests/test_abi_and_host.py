@@ -119,14 +119,41 @@ def test_synthetic_inputs_are_counter_based(spe):
 @pytest.mark.parametrize("std", ["c++11", "c++17"])
 def test_caller_text_written_against_the_reference_api_compiles(tmp_path, std):
     """north_star: 'drops into Rock as-is'.  tests/cpp/reference_caller_text.cpp holds caller statements typed against
-    the reference's Eigen / MTK API (assignable blocks, setZero, MTK::SO3<double>(q), Eigen::Matrix<...> spellings);
+    the reference's Eigen / MTK API (assignable blocks, setZero, MTK::SO3<double>::exp, MTK::subblock / setDiagonal,
+    PoseUKF::MTK_UKF::cov, WState operator+ / operator-, boxplus / boxminus, Eigen::Matrix<...> spellings);
     they must compile -- warnings as errors -- against include/ unchanged and give the reference's results."""
     import subprocess
     exe = tmp_path / "caller_text"
     subprocess.check_call(["g++", f"-std={std}", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "reference_caller_text.cpp"), "-o", str(exe)])
+                           os.path.join(ROOT, "tests", "cpp", "reference_caller_text.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "slam-pose_estimation_amd", "lib"), "-lukf_batch",
+                           "-Wl,-rpath," + os.path.join(ROOT, "slam-pose_estimation_amd", "lib")])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+    # the MTK::SO3 host conveniences (pose_estimation/Manifold.hpp: exp, log, boxplus with scale, boxminus) against scipy's
+    # Rotation -- an independent implementation (MTK itself is not vendored with the reference: unpinned, SURVEY Appendix A.1)
+    from scipy.spatial.transform import Rotation
+    dump = subprocess.run([str(exe), "dump"], capture_output=True, text=True, timeout=60)
+    assert dump.returncode == 0
+    rows = [[float(t) for t in line.split() if t[0] in "-0123456789" and t not in ("->",)] for line in dump.stdout.strip().splitlines()]
+    kinds = [line.split()[0] for line in dump.stdout.strip().splitlines()]
+    assert kinds.count("exp") == 8 and kinds.count("boxplus") == 8
+    prev_q = None
+    for kind, r in zip(kinds, rows):
+        if kind == "exp":
+            v, q, back = np.array(r[0:3]), np.array(r[3:7]), np.array(r[7:10])
+            q_ref = Rotation.from_rotvec(v).as_quat()          # (x, y, z, w), w >= 0 for |v| <= pi
+            assert np.abs(q - q_ref).max() < 1e-15
+            # MTK's log is atan based: angle in (-pi, pi), i.e. scipy's rotation vector for |v| < pi
+            assert np.abs(back - Rotation.from_quat(q_ref).as_rotvec()).max() < 1e-14
+            prev_q = q
+        else:
+            w, scale, p, diff = np.array(r[0:3]), r[3], np.array(r[4:8]), np.array(r[8:11])
+            p_ref = (Rotation.from_quat(prev_q) * Rotation.from_rotvec(scale * w)).as_quat()
+            p_ref = p_ref if np.dot(p_ref, p) > 0 else -p_ref
+            assert np.abs(p - p_ref).max() < 1e-15
+            # boxminus = log(q^-1 p) = the scaled increment (|scale w| < pi here)
+            assert np.abs(diff - scale * w).max() < 1e-14
 
 
 def test_new_entry_points_reject_a_null_engine(spe):

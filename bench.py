@@ -48,6 +48,7 @@ BURST_STEPS = 20
 RECENT_CYCLES = 16                 # window of the second in-run parity check
 MULTI_CYCLES = 8                   # cycles per launch of the extra multi-cycle region (ukfb_cycle_multi_dev)
 TOL = {"f64": 1e-9, "f32": 1e-4}   # north_star
+F32_HORIZON = {"pose": 500, "orient": 150}   # cycles the fp32 engines stay within 1e-4 of the fp64 oracle (tests/test_gpu_f32_horizon.py)
 
 
 class _DevArray:
@@ -69,6 +70,9 @@ def parse():
                     help="strong: --filters filters are sharded evenly over the ranks (the metric's '1 M filters on "
                          "1/2/4/8 GPUs'); weak: every rank runs --filters filters (N x --filters in total)")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--wide-arithmetic", type=int, choices=[0, 1], default=0,
+                    help="with --precision f32: 1 = fp32 arrays in HBM, every instruction of the cycle in fp64 "
+                         "(ukfb_config.wide_arithmetic); the line then reports dtype f64 and config.hbm_format f32")
     ap.add_argument("--lanes-per-filter", type=int, default=0, help="16/32/64 (0: engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -309,6 +313,16 @@ def parity_check(args, spe, eng, first, sample, cycles, orient, start=None):
         out["float_oracle_vs_fp64"] = {"max_abs_mu": fm, "max_abs_cov": fc}
         out["gpu_vs_float_oracle"] = {"max_abs_mu": float(np.abs(m_g - m_f).max()), "max_abs_cov": float(np.abs(c_g - c_f).max())}
         out["explained_by_fp32_arithmetic"] = bool(em <= max(2 * fm, 2e-6) and ec <= max(2 * fc, 2e-6))
+        if not getattr(args, "wide_arithmetic", 0):
+            # what fp32 ARITHMETIC holds on these workloads (tests/test_gpu_f32_horizon.py); past it the recursion's own fp32
+            # rounding exceeds 1e-4 whatever the kernel does (tests/study_f32_mixed.py, profiles/r04_f32_mixed_ab.txt)
+            hz = F32_HORIZON["orient" if orient else "pose"]
+            out["horizon_cycles"] = hz
+            out["within_horizon"] = bool(cycles - k0 <= hz)
+            out["sample"] += (f"; fp32 arithmetic holds north_star's 1e-4 on this workload for {hz} cycles from a common state -- this check "
+                              f"spans {cycles - k0}" + ("" if cycles - k0 <= hz else
+                              " (beyond it: the distance is fp32 rounding of the recursion itself, see float_oracle_vs_fp64; "
+                              "--wide-arithmetic 1 keeps the fp32 HBM format and holds 1e-4 over the whole run)"))
     return out
 
 
@@ -397,6 +411,7 @@ def run_rank(args):
     coll_dev = dev if (args.backend == "nccl" and have_gpu) else torch.device("cpu")
 
     prec = spe.F64 if args.precision == "f64" else spe.F32
+    wide = 1 if (args.wide_arithmetic and prec == spe.F32) else 0
     tdtype = torch.float64 if prec == spe.F64 else torch.float32
     total = args.filters * world if args.scaling == "weak" else args.filters
     first, per = spe.shard_range(total, world, rank)
@@ -446,13 +461,13 @@ def run_rank(args):
         sy = spe.synth
         eng = spe.BatchOrientationUKF(per, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec,
                                       device=dev.index, lanes_per_filter=args.lanes_per_filter, stream="private",
-                                      split_streams=args.split_streams)
+                                      split_streams=args.split_streams, wide_arithmetic=wide)
         eng.set_process_noise(sy.orient_process_noise())
     else:
         # (tracking inputs: the engine runs on torch's current stream, the per-step generator kernel is a torch op ordered with it)
         eng = spe.BatchPoseUKF(per, precision=prec, device=dev.index, lanes_per_filter=args.lanes_per_filter,
                                stream=None if tracking else "private",
-                               bucket_models=args.bucket_models, split_streams=args.split_streams)
+                               bucket_models=args.bucket_models, split_streams=args.split_streams, wide_arithmetic=wide)
     # input rings [N_RING][filters][..], contiguous (a multi-cycle launch addresses its slots inside them); *_d: the slots
     acc_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev)
     gyr_ring = torch.empty((N_RING, per, 3), dtype=tdtype, device=dev) if orient else None
@@ -572,6 +587,7 @@ def run_rank(args):
     if not args.no_extra_regions:
         snap = (mu_view.clone(), cov_view.clone(), done[0])
         torch.cuda.synchronize()
+    fence()                     # every rank starts its clock behind the same barrier, with nothing queued on its device
     eng.timer_begin()           # HIP events on the stream the kernel is launched on
     t0 = time.perf_counter()
     launches = run_cycles(args.steps)
@@ -583,13 +599,32 @@ def run_rank(args):
     # latency (an all-reduce over 8 GPUs) is not part of K steps -- at N = 8 a 20-step region of the 1 M-filter batch is 2.7 ms.
     elapsed_local = time.perf_counter() - t0
     fence()
+    elapsed_barrier = time.perf_counter() - t0    # barrier to barrier: K steps + the closing barrier's own latency (rounds 1-2's definition)
     elapsed = elapsed_local
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rank_lo, rank_hi = rank_stats(elapsed_local / args.steps * 1e3)
+    _, barrier_hi = rank_stats(elapsed_barrier / args.steps * 1e3)
     status_or = eng.status_summary()
+    # which device every rank ran on (the driver's SCALE line verifies itself: N distinct devices, N RCCL ranks)
+    rank_devices = None
+    try:
+        me = {"rank": rank, "device": (dev.index if have_gpu else None)}
+        if have_gpu:
+            pr = torch.cuda.get_device_properties(dev)
+            me["name"] = pr.name
+            me["uuid"] = str(getattr(pr, "uuid", "")) or None
+            me["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+        if dist is not None:
+            allv = [None] * world
+            dist.all_gather_object(allv, me)
+            rank_devices = allv
+        else:
+            rank_devices = [me]
+    except Exception as ex:   # (a diagnostic: never fail a measurement over it)
+        rank_devices = [{"error": repr(ex)}]
 
     # ---- in-run parity on rank 0's first filters (before anything else advances the state)
     parity = parity_recent = None
@@ -717,7 +752,7 @@ def run_rank(args):
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": args.precision,
+            "dtype": "f64" if wide else args.precision,
             "data": "synthetic",
             "config": {"workload": (f"{total} OrientationState UKF filters, fused predict(gyro+acc, dt=0.01)"
                                     f"+body-velocity update per step, {args.precision}, {per} filters per GPU" if orient else
@@ -727,6 +762,7 @@ def run_rank(args):
                                        else "PositionMeasurement") + f" update per step, {args.precision}, {per} filters per GPU"
                                     + (", position fixes regenerated per step around the filter's own mean (--inputs tracking)" if tracking else "")),
                        "filters": total, "filters_per_gpu": per,
+                       "hbm_format": args.precision, "arithmetic": "f64" if (wide or args.precision == "f64") else "f32",
                        "lanes_per_filter": 64 // max(1, info["filters_per_workgroup"]),
                        "parallelism": f"filter-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -752,6 +788,8 @@ def run_rank(args):
             "rccl_ranks": (dist.get_world_size() if (dist is not None and args.backend == "nccl") else None),
             "backend": (args.backend if dist is not None else None),
             "ms_per_step_rank_min": rank_lo, "ms_per_step_rank_max": rank_hi,
+            "ms_per_step_barrier": barrier_hi,
+            "rank_devices": rank_devices,
             "gather_ms": gather_ms,
             "parity": parity,
             "parity_recent": parity_recent,

@@ -120,6 +120,14 @@ typedef struct ukfb_config {
                              * launch overlaps the head of the next (small launches lose 4-8 % to their partly empty last
                              * round of workgroups otherwise).  Bit-identical results; every other call joins the two streams
                              * first.  Engines on a caller's stream never split: plain stream order holds for them.        */
+    int32_t wide_arithmetic; /* fp32 engines, tuned layout only; 0 (default) = fp32 arithmetic.  1 = the state, the inputs and the
+                             * noise tables keep their fp32 format in HBM (same footprint, same C-ABI arrays), but every
+                             * instruction of predict / update runs in fp64: values widen on load and narrow on commit.  The
+                             * reference computes in fp64 throughout (Measurement.hpp:9-10); an fp32 evaluation of its recursion
+                             * leaves the fp64 one by more than 1e-4 after 150 (OrientationState) / 500 (PoseWithVelocity)
+                             * cycles of the bench workloads, and no cheaper mix of precisions holds it (DESIGN.md section 3,
+                             * profiles/r04_f32_mixed_ab.txt).  This mode does, at the fp64 engine's rate.  Ignored by fp64
+                             * engines; ukfb_set_config refuses it together with lanes_per_filter 32 / 64.                     */
 } ukfb_config;
 
 int ukfb_default_config(ukfb_config* cfg);
@@ -370,8 +378,12 @@ int ukfb_group_timer_end(ukfb_group* g, float* elapsed_ms_max, float* elapsed_ms
  * states of ALL filters in batch order on every device: ncclAllGather over one communicator per device (ncclCommInitAll at
  * the first call; RCCL is loaded at run time, librccl.so.1).  Stream-ordered after the launches enqueued so far; complete
  * after ukfb_group_sync.  Gather at the end of a run or every K cycles, not per cycle: at 131 072 Pose filters per device
- * the means are 6.8 MB (fp32) per shard, about the duration of one cycle over xGMI.  Needs one shard per device. */
+ * the means are 6.8 MB (fp32) per shard, about the duration of one cycle over xGMI.  A group whose shards SHARE a device
+ * (where RCCL has no rank to give them; e.g. a rehearsal of N shards on one GPU) exchanges by peer copies between the shards'
+ * streams instead; staging and the ragged compaction are the same code either way.  ukfb_group_last_gather_exchange tells
+ * which exchange the last gather used: 1 = RCCL all-gather, 2 = peer copies, 0 = no gather yet, -1 = NULL group. */
 int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev);
+int ukfb_group_last_gather_exchange(const ukfb_group* g);
 
 /* ---- measurement of the engine itself ---------------------------------------------------- */
 /* name, dynamic LDS bytes per workgroup, filters per workgroup and grid size of the kernel the

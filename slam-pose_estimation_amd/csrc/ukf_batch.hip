@@ -184,10 +184,11 @@ int launch(ukfb_engine* e, const ukfb::LaunchReq& r) {
     ON_DEVICE(e->device);
     if (r.wait_event) HIP_TRY(hipStreamWaitEvent(ukfb::main_stream(e), r.wait_event, 0));
     int rc;
+    const bool wide = e->prec == UKFB_F32 && e->cfg.wide_arithmetic != 0;   // fp32 arrays, fp64 arithmetic (tuned layout only)
     if (e->model == UKFB_MODEL_POSE)
-        rc = e->prec == UKFB_F64 ? ukfb::launch_pose_f64(e, r) : ukfb::launch_pose_f32(e, r);
+        rc = e->prec == UKFB_F64 ? ukfb::launch_pose_f64(e, r) : (wide ? ukfb::launch_pose_f32w(e, r) : ukfb::launch_pose_f32(e, r));
     else
-        rc = e->prec == UKFB_F64 ? ukfb::launch_orient_f64(e, r) : ukfb::launch_orient_f32(e, r);
+        rc = e->prec == UKFB_F64 ? ukfb::launch_orient_f64(e, r) : (wide ? ukfb::launch_orient_f32w(e, r) : ukfb::launch_orient_f32(e, r));
     if (!rc && r.done_event) HIP_TRY(hipEventRecord(r.done_event, ukfb::main_stream(e)));
     return rc;
 }
@@ -207,13 +208,35 @@ struct Staged {
 int ensure_copy_path(ukfb_engine* e) {
     if (e->copy_stream) return UKFB_OK;
     const size_t n = size_t(e->cap), ts = e->tsize;
+    // everything into locals; the engine sees the set only when all of it exists (a failure frees what was created and a
+    // retry starts from nothing -- no leaked stream / events / buffers, no half-initialised handles)
     hipStream_t cs = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipEvent_t evc[2] = {nullptr, nullptr}, evu[2] = {nullptr, nullptr};
+    void* zs[2] = {nullptr, nullptr};
+    void* qs[2] = {nullptr, nullptr};
+    hipError_t err = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    for (int s = 0; s < 2 && err == hipSuccess; ++s) {
+        err = hipEventCreateWithFlags(&evc[s], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&evu[s], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipMalloc(&zs[s], n * 3 * ts);
+        if (err == hipSuccess) err = hipMalloc(&qs[s], n * 9 * ts);
+    }
+    if (err != hipSuccess) {
+        for (int s = 0; s < 2; ++s) {
+            if (zs[s]) (void)hipFree(zs[s]);
+            if (qs[s]) (void)hipFree(qs[s]);
+            if (evc[s]) (void)hipEventDestroy(evc[s]);
+            if (evu[s]) (void)hipEventDestroy(evu[s]);
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+        ukfb::set_error("host-fed cycles: copy stream / staging", err);
+        return UKFB_ERR_HIP;
+    }
     for (int s = 0; s < 2; ++s) {
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_copy[s], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_used[s], hipEventDisableTiming));
-        HIP_TRY(hipMalloc(&e->zc_stage[s], n * 3 * ts));
-        HIP_TRY(hipMalloc(&e->Qc_stage[s], n * 9 * ts));
+        e->ev_copy[s] = evc[s];
+        e->ev_used[s] = evu[s];
+        e->zc_stage[s] = zs[s];
+        e->Qc_stage[s] = qs[s];
     }
     e->copy_stream = cs;
     return UKFB_OK;
@@ -485,8 +508,10 @@ __global__ void events_gather_kernel(const int64_t* filt, const int64_t* ts, con
 
 
 // ---- model-class buckets (ukfb_cycle_dev with per-filter model ids) ---------------------------------------
-// A stable three-way partition (by update_class above) of the filter indices, two passes over the model ids: (1) per-block class counts, (2) every
-// block finds its offsets by summing the counts of the blocks before it (a few thousand values at most) and scatters.  The
+// A stable three-way partition (by update_class above) of the filter indices, two passes over the model ids: (1) per-block class
+// counts, (2) ONE block turns them into exclusive prefix sums and class totals (3 x blocks values: 120 000 at the 40-million-
+// filter capacity the tests exercise; every scatter block re-summing all of them was quadratic in the batch size), (3) every
+// block scatters from its offsets.  The
 // classes follow each other from the most expensive to the cheapest, each
 // starts at a multiple of 4 (one wavefront = 4 filters); the list was pre-filled with -1, so the gaps read as padding.
 constexpr int BK_THREADS = 256, BK_PER_THREAD = 4, BK_BLOCK = BK_THREADS * BK_PER_THREAD;
@@ -515,35 +540,41 @@ __global__ void __launch_bounds__(BK_THREADS) bucket_count_kernel(const int32_t*
         counts[2 * nblocks + blockIdx.x] = n2;
     }
 }
-__global__ void __launch_bounds__(BK_THREADS) bucket_scatter_kernel(const int32_t* meas, int64_t n, int engine_model,
-                                                                    const uint32_t* counts, int nblocks, int32_t* order) {
-    using Scan = hipcub::BlockScan<uint32_t, BK_THREADS>;
-    using Reduce = hipcub::BlockReduce<uint32_t, BK_THREADS>;
-    __shared__ typename Scan::TempStorage stmp;
-    __shared__ typename Reduce::TempStorage rtmp;
-    __shared__ uint32_t start[3];
-    // totals of every class and the counts of the blocks before this one
-    uint32_t before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += BK_THREADS)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t v = counts[c * nblocks + b];
-            total[c] += v;
-            before[c] += (b < int(blockIdx.x)) ? v : 0u;
-        }
-#pragma unroll
+// exclusive prefix sums of the per-block counts, class by class: before[c * nblocks + b] = sum of counts[c][0 .. b), total[c]
+constexpr int BS_THREADS = 1024;
+__global__ void __launch_bounds__(BS_THREADS) bucket_scan_kernel(const uint32_t* counts, int nblocks, uint32_t* before, uint32_t* total) {
+    using Scan = hipcub::BlockScan<uint32_t, BS_THREADS>;
+    __shared__ typename Scan::TempStorage tmp;
+    __shared__ uint32_t carry;
     for (int c = 0; c < 3; ++c) {
-        total[c] = Reduce(rtmp).Sum(total[c]);
+        if (threadIdx.x == 0) carry = 0;
         __syncthreads();
-        before[c] = Reduce(rtmp).Sum(before[c]);
+        for (int b0 = 0; b0 < nblocks; b0 += BS_THREADS) {
+            const int b = b0 + int(threadIdx.x);
+            const uint32_t v = b < nblocks ? counts[c * nblocks + b] : 0u;
+            uint32_t ex, tile;
+            Scan(tmp).ExclusiveSum(v, ex, tile);
+            if (b < nblocks) before[c * nblocks + b] = carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) carry += tile;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) total[c] = carry;
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(BK_THREADS) bucket_scatter_kernel(const int32_t* meas, int64_t n, int engine_model,
+                                                                    const uint32_t* before, const uint32_t* total, int nblocks,
+                                                                    int32_t* order) {
+    using Scan = hipcub::BlockScan<uint32_t, BK_THREADS>;
+    __shared__ typename Scan::TempStorage stmp;
+    __shared__ uint32_t start[3];
     if (threadIdx.x == 0) {
         // the most expensive class first: the cheap wavefronts fill the tail of the launch
         const uint32_t b1 = (total[2] + 3u) & ~3u, b0 = b1 + ((total[1] + 3u) & ~3u);
-        start[2] = before[2];
-        start[1] = b1 + before[1];
-        start[0] = b0 + before[0];
+        start[2] = before[2 * nblocks + blockIdx.x];
+        start[1] = b1 + before[nblocks + blockIdx.x];
+        start[0] = b0 + before[blockIdx.x];
     }
     __syncthreads();
     const int64_t base = int64_t(blockIdx.x) * BK_BLOCK + int64_t(threadIdx.x) * BK_PER_THREAD;
@@ -572,15 +603,30 @@ int build_model_buckets(ukfb_engine* e, const int32_t* meas_dev, int64_t* items)
     const int64_t n = e->cap;
     const int nblocks = int((n + BK_BLOCK - 1) / BK_BLOCK);
     const size_t list = size_t(n) + 16;
-    if (!e->bucket_idx) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->bucket_idx), list * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->bucket_counts), size_t(3) * nblocks * sizeof(uint32_t)));
+    if (!e->bucket_idx || !e->bucket_counts) {
+        // both or neither: the engine sees the pair only when every allocation succeeded (a half-published pair would let the
+        // next call skip the allocation and launch through a null pointer)
+        int32_t* idx = nullptr;
+        uint32_t* cnt = nullptr;   // [3][blocks] counts, [3][blocks] exclusive prefix sums, [3] totals (+ 1 pad)
+        if (hipMalloc(reinterpret_cast<void**>(&idx), list * sizeof(int32_t)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&cnt), (size_t(6) * nblocks + 4) * sizeof(uint32_t)) != hipSuccess) {
+            if (idx) (void)hipFree(idx);
+            return fail(UKFB_ERR_HIP, "model buckets: device allocation failed");
+        }
+        if (e->bucket_idx) (void)hipFree(e->bucket_idx);
+        if (e->bucket_counts) (void)hipFree(e->bucket_counts);
+        e->bucket_idx = idx;
+        e->bucket_counts = cnt;
     }
+    uint32_t* const before = e->bucket_counts + size_t(3) * nblocks;
+    uint32_t* const total = e->bucket_counts + size_t(6) * nblocks;
     HIP_TRY(hipMemsetAsync(e->bucket_idx, 0xFF, list * sizeof(int32_t), ukfb::main_stream(e)));
     hipLaunchKernelGGL(bucket_count_kernel, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model, e->bucket_counts,
                        nblocks);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(BS_THREADS), 0, ukfb::main_stream(e), static_cast<const uint32_t*>(e->bucket_counts),
+                       nblocks, before, total);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model,
-                       static_cast<const uint32_t*>(e->bucket_counts), nblocks, e->bucket_idx);
+                       static_cast<const uint32_t*>(before), static_cast<const uint32_t*>(total), nblocks, e->bucket_idx);
     HIP_TRY(hipGetLastError());
     *items = (n + 3 + 3 + 3) / 4 * 4;   // sum of three counts each rounded up to 4 <= n + 9, itself rounded up to whole wavefronts
     return UKFB_OK;
@@ -664,6 +710,7 @@ int ukfb_default_config(ukfb_config* cfg) {
     cfg->lanes_per_filter = 16;
     cfg->bucket_models = 1;
     cfg->split_streams = 1;
+    cfg->wide_arithmetic = 0;
     return UKFB_OK;
 }
 
@@ -809,6 +856,9 @@ int ukfb_set_config(ukfb_engine* e, const ukfb_config* cfg) {
     if (!ukfb_layout_supported(e->prec, c.lanes_per_filter))
         return fail(UKFB_ERR_INVALID_ARG, "lanes_per_filter 32 / 64 in fp64 is a diagnostic build option (make GENERIC_F64=1)");
     if (c.mean_max_iter < 1) return fail(UKFB_ERR_INVALID_ARG, "mean_max_iter must be >= 1");
+    if (c.wide_arithmetic != 0 && c.wide_arithmetic != 1) return fail(UKFB_ERR_INVALID_ARG, "wide_arithmetic must be 0 or 1");
+    if (c.wide_arithmetic && e->prec == UKFB_F32 && c.lanes_per_filter != 16)
+        return fail(UKFB_ERR_INVALID_ARG, "wide_arithmetic runs on the tuned layout only (lanes_per_filter 16)");
     e->cfg = c;
     return UKFB_OK;
 }

@@ -386,6 +386,7 @@ template <class T> struct ProcIn {
 // PoseWithVelocity (PoseWithVelocity.hpp:18-23): p[0..2] q[3..6] v[7..9] w[10..12]
 // ---------------------------------------------------------------------------------------------
 template <class T> struct PoseM {
+    template <class U> using rebind = PoseM<U>;   // the same manifold over another scalar (wide-arithmetic kernels)
     static constexpr int S = 13, D = 12, MODEL = 0;
     enum { P = 0, Q = 3, V = 7, W = 10 };
 
@@ -465,6 +466,7 @@ template <class T> struct PoseM {
 // OrientationState (OrientationState.hpp:20-26): q[0..3] v[4..6] bg[7..9] ba[10..12] g[13]
 // ---------------------------------------------------------------------------------------------
 template <class T> struct OrientM {
+    template <class U> using rebind = OrientM<U>;
     static constexpr int S = 14, D = 13, MODEL = 1;
 
     static UKFB_DEV void boxplus(T (&x)[14], const T (&d)[13]) {

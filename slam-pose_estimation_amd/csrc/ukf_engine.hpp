@@ -133,6 +133,8 @@ int launch_pose_f64(ukfb_engine* e, const LaunchReq& r);
 int launch_pose_f32(ukfb_engine* e, const LaunchReq& r);
 int launch_orient_f64(ukfb_engine* e, const LaunchReq& r);
 int launch_orient_f32(ukfb_engine* e, const LaunchReq& r);
+int launch_pose_f32w(ukfb_engine* e, const LaunchReq& r);     // fp32 engines, wide arithmetic (ukfb_config::wide_arithmetic)
+int launch_orient_f32w(ukfb_engine* e, const LaunchReq& r);
 
 void set_error(const char* what, hipError_t err);
 void set_error_text(const std::string& text);   // what ukfb_last_error() returns on this thread

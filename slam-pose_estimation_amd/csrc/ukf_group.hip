@@ -67,6 +67,8 @@ struct ukfb_group {
     // result gather: one communicator per shard (created at the first gather), padded staging per shard
     std::vector<ncclComm_t> comms;
     std::vector<void*> send_pad, recv_pad;
+    std::vector<hipEvent_t> staged, pulled;   // copy exchange (shards sharing a device): shard s staged / shard r pulled every block
+    int last_gather_exchange = 0;             // 0 none yet, 1 RCCL all-gather, 2 peer copies
     int64_t max_count = 0;
     // event routing (ukfb_group_process_events): one pinned, grow-only buffer per shard
     std::vector<void*> route_buf;
@@ -102,9 +104,13 @@ void release_gather(ukfb_group* g) {
         ukfb::DeviceScope on_device(g->devices[r]);
         if (g->send_pad[r]) (void)hipFree(g->send_pad[r]);
         if (g->recv_pad[r]) (void)hipFree(g->recv_pad[r]);
+        if (r < g->staged.size() && g->staged[r]) (void)hipEventDestroy(g->staged[r]);
+        if (r < g->pulled.size() && g->pulled[r]) (void)hipEventDestroy(g->pulled[r]);
     }
     g->send_pad.clear();
     g->recv_pad.clear();
+    g->staged.clear();
+    g->pulled.clear();
 }
 
 // Host-array calls over a large batch: every shard's call stages and uploads its range, which occupies the calling thread
@@ -558,40 +564,17 @@ int ukfb_group_timer_end(ukfb_group* g, float* elapsed_ms_max, float* elapsed_ms
     return UKFB_OK;
 }
 
-// ---- result gather: RCCL all-gather of the mean states over xGMI.  out_dev[r] (device r, engine precision, [total][S])
-// receives the means of ALL filters in batch order.  Shards may differ by one filter (ukfb_group_shard_range): the
-// collective runs on buffers padded to the largest shard, one device-to-device copy per shard compacts the result.
-int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
-    if (!g || !out_dev) return UKFB_ERR_INVALID_ARG;
-    const size_t n = g->engines.size();
-    Rccl& rc = rccl();
-    if (!rc.ok()) return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: RCCL (librccl.so.1) could not be loaded");
-    for (size_t a = 0; a < n; ++a)
-        for (size_t b = a + 1; b < n; ++b)
-            if (g->devices[a] == g->devices[b])
-                return gfail(UKFB_ERR_INVALID_ARG, "ukfb_group_gather_means: two shards share a device (RCCL needs one rank per device); "
-                                                   "read the shards with ukfb_group_get_state instead");
-    const size_t row = size_t(g->S) * g->tsize, pad_bytes = size_t(g->max_count) * row;
-    if (g->comms.empty()) {
-        g->comms.assign(n, nullptr);
-        const ncclResult_t st = rc.CommInitAll(g->comms.data(), int(n), g->devices.data());
-        if (st != ncclSuccess) {
-            g->comms.clear();
-            return gfail(UKFB_ERR_HIP, std::string("ncclCommInitAll: ") + rc.GetErrorString(st));
-        }
-        g->send_pad.assign(n, nullptr);
-        g->recv_pad.assign(n, nullptr);
-        for (size_t r = 0; r < n; ++r) {
-            ukfb::DeviceScope on_device(g->devices[r]);
-            if (on_device.err != hipSuccess || hipMalloc(&g->send_pad[r], pad_bytes) != hipSuccess ||
-                hipMalloc(&g->recv_pad[r], pad_bytes * n) != hipSuccess || hipMemset(g->send_pad[r], 0, pad_bytes) != hipSuccess) {
-                release_gather(g);
-                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging allocation failed");
-            }
-        }
-    }
-    // every shard: mean -> padded send buffer on its own stream (ordered after the launches enqueued so far)
-    std::vector<hipStream_t> streams(n);
+// ---- result gather.  out_dev[r] (device r, engine precision, [total][S]) receives the means of ALL filters in batch order.
+// Shards may differ by one filter (ukfb_group_shard_range), so the exchange runs on buffers padded to the largest shard:
+//   1. stage    every shard copies its means into its padded send buffer           (its own stream)
+//   2. exchange recv_pad[r] = [send_pad[0] | send_pad[1] | ...] on every device    (RCCL all-gather over xGMI; shards that
+//               share a device -- where RCCL has no rank to give them -- exchange by peer copies instead)
+//   3. compact  one copy per shard takes the padding out: out[first[s] ...] = recv_pad[r][s]   (ragged shards)
+// Steps 1 and 3 are the same code for both exchanges, so a one-GPU box exercises them with N > 1 shards
+// (tests/test_gpu_group.py: 2, 3 and 8 shards on device 0, ragged totals).
+namespace {
+int gather_stage(ukfb_group* g, std::vector<hipStream_t>& streams) {
+    const size_t n = g->engines.size(), row = size_t(g->S) * g->tsize;
     for (size_t r = 0; r < n; ++r) {
         ukfb_engine* e = g->engines[r];
         ukfb::DeviceScope on_device(g->devices[r]);
@@ -600,6 +583,12 @@ int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
         if (hipMemcpyAsync(g->send_pad[r], e->mu, size_t(g->count[r]) * row, hipMemcpyDeviceToDevice, streams[r]) != hipSuccess)
             return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging copy failed");
     }
+    return UKFB_OK;
+}
+
+int gather_exchange_rccl(ukfb_group* g, const std::vector<hipStream_t>& streams) {
+    Rccl& rc = rccl();
+    const size_t n = g->engines.size();
     const ncclDataType_t dt = g->prec == UKFB_F64 ? ncclFloat64 : ncclFloat32;
     ncclResult_t st = rc.GroupStart();
     for (size_t r = 0; r < n && st == ncclSuccess; ++r)
@@ -607,16 +596,99 @@ int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
     const ncclResult_t st2 = rc.GroupEnd();
     if (st != ncclSuccess || st2 != ncclSuccess)
         return gfail(UKFB_ERR_HIP, std::string("ncclAllGather: ") + rc.GetErrorString(st != ncclSuccess ? st : st2));
+    return UKFB_OK;
+}
+
+// Shards on one device (or any device list RCCL cannot take): stream r pulls every shard's padded block once that shard's
+// staging copy has finished (one event per shard).
+int gather_exchange_copies(ukfb_group* g, const std::vector<hipStream_t>& streams) {
+    const size_t n = g->engines.size(), pad_bytes = size_t(g->max_count) * size_t(g->S) * g->tsize;
+    for (size_t s = 0; s < n; ++s) {
+        ukfb::DeviceScope on_device(g->devices[s]);
+        if (on_device.err != hipSuccess || hipEventRecord(g->staged[s], streams[s]) != hipSuccess)
+            return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: event record failed");
+    }
+    for (size_t r = 0; r < n; ++r) {
+        ukfb::DeviceScope on_device(g->devices[r]);
+        if (on_device.err != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
+        for (size_t s = 0; s < n; ++s) {
+            if (s != r && hipStreamWaitEvent(streams[r], g->staged[s], 0) != hipSuccess)
+                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: stream wait failed");
+            if (hipMemcpyPeerAsync(static_cast<char*>(g->recv_pad[r]) + s * pad_bytes, g->devices[r], g->send_pad[s], g->devices[s],
+                                   pad_bytes, streams[r]) != hipSuccess)
+                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: exchange copy failed");
+        }
+    }
+    // (a later staging copy of shard s must not overwrite send_pad[s] while another stream still reads it)
+    for (size_t r = 0; r < n; ++r) {
+        ukfb::DeviceScope on_device(g->devices[r]);
+        if (on_device.err != hipSuccess || hipEventRecord(g->pulled[r], streams[r]) != hipSuccess)
+            return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: event record failed");
+    }
+    for (size_t s = 0; s < n; ++s)
+        for (size_t r = 0; r < n; ++r)
+            if (r != s && hipStreamWaitEvent(streams[s], g->pulled[r], 0) != hipSuccess)
+                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: stream wait failed");
+    return UKFB_OK;
+}
+
+int gather_compact(ukfb_group* g, const std::vector<hipStream_t>& streams, void* const* out_dev) {
+    const size_t n = g->engines.size(), row = size_t(g->S) * g->tsize, pad_bytes = size_t(g->max_count) * row;
     for (size_t r = 0; r < n; ++r) {
         ukfb::DeviceScope on_device(g->devices[r]);
         if (on_device.err != hipSuccess) return gfail(UKFB_ERR_HIP, "hipSetDevice");
         for (size_t s = 0; s < n; ++s)
-            if (hipMemcpyAsync(static_cast<char*>(out_dev[r]) + size_t(g->first[s]) * row,
+            if (g->count[s] > 0 &&
+                hipMemcpyAsync(static_cast<char*>(out_dev[r]) + size_t(g->first[s]) * row,
                                static_cast<const char*>(g->recv_pad[r]) + s * pad_bytes, size_t(g->count[s]) * row,
                                hipMemcpyDeviceToDevice, streams[r]) != hipSuccess)
                 return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: compaction copy failed");
     }
-    return UKFB_OK;   // stream-ordered: ukfb_group_sync (or the shard's stream) completes it
+    return UKFB_OK;
 }
+}  // namespace
+
+int ukfb_group_gather_means(ukfb_group* g, void* const* out_dev) {
+    if (!g || !out_dev) return UKFB_ERR_INVALID_ARG;
+    const size_t n = g->engines.size();
+    bool shared = false;   // two shards on one device: RCCL wants one rank per device
+    for (size_t a = 0; a < n; ++a)
+        for (size_t b = a + 1; b < n; ++b) shared = shared || g->devices[a] == g->devices[b];
+    const size_t row = size_t(g->S) * g->tsize, pad_bytes = size_t(g->max_count) * row;
+    if (g->send_pad.empty()) {
+        if (!shared) {
+            Rccl& rc = rccl();
+            if (!rc.ok()) return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: RCCL (librccl.so.1) could not be loaded");
+            g->comms.assign(n, nullptr);
+            const ncclResult_t st = rc.CommInitAll(g->comms.data(), int(n), g->devices.data());
+            if (st != ncclSuccess) {
+                g->comms.clear();
+                return gfail(UKFB_ERR_HIP, std::string("ncclCommInitAll: ") + rc.GetErrorString(st));
+            }
+        }
+        g->send_pad.assign(n, nullptr);
+        g->recv_pad.assign(n, nullptr);
+        g->staged.assign(n, nullptr);
+        g->pulled.assign(n, nullptr);
+        for (size_t r = 0; r < n; ++r) {
+            ukfb::DeviceScope on_device(g->devices[r]);
+            if (on_device.err != hipSuccess || hipMalloc(&g->send_pad[r], pad_bytes) != hipSuccess ||
+                hipMalloc(&g->recv_pad[r], pad_bytes * n) != hipSuccess || hipMemset(g->send_pad[r], 0, pad_bytes) != hipSuccess ||
+                hipEventCreateWithFlags(&g->staged[r], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g->pulled[r], hipEventDisableTiming) != hipSuccess) {
+                release_gather(g);
+                return gfail(UKFB_ERR_HIP, "ukfb_group_gather_means: staging allocation failed");
+            }
+        }
+    }
+    std::vector<hipStream_t> streams(n);
+    int rc = gather_stage(g, streams);
+    if (!rc) rc = shared ? gather_exchange_copies(g, streams) : gather_exchange_rccl(g, streams);
+    if (!rc) rc = gather_compact(g, streams, out_dev);
+    g->last_gather_exchange = shared ? 2 : 1;
+    return rc;   // stream-ordered: ukfb_group_sync (or the shard's stream) completes it
+}
+
+int ukfb_group_last_gather_exchange(const ukfb_group* g) { return g ? g->last_gather_exchange : -1; }
 
 }  // extern "C"

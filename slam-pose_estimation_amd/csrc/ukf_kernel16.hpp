@@ -303,11 +303,11 @@ template <class T, class M> constexpr int lds_bytes_per_filter16() { return Layo
 //          then the offsets the affine entries are read from.  Row 16 = every store to the sink: the row of a lane
 //          whose filter does not commit its prediction, so that the stores need no predicate of their own.
 // ---------------------------------------------------------------------------------------------
-template <class T, class M> struct CovTab {
+template <class T, class M, class TS = T> struct CovTab {
     using LY = Layout16<T, M>;
     static constexpr int D = M::D, NL = LY::NL, ST = LY::ST, TRIP = LY::TRIP, TR = MT<M>::TR, TC = MT<M>::TC;
     static constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + 15) / 16;
-    static constexpr int NRD = 8, NWR = 16, SZ = int(sizeof(T));
+    static constexpr int NRD = 8, NWR = 16, SZ = int(sizeof(T)), SZG = int(sizeof(TS));   // LDS scalars / HBM scalars
     static constexpr int RD_PR = 0, RD_PC = 1, RD_WS = 2, RD_NZ = 4, RD_ANZ = 5;   // rd row (RD_WS: one or two dwords)
     static constexpr int WR_TILE = 0, WR_AFF = TR * TC, WR_AFF_RD = TR * TC + AEL;  // wr row
     static_assert(RD_ANZ + AEL <= NRD && WR_AFF_RD + AEL <= NWR, "covariance lane tables");
@@ -337,7 +337,7 @@ template <class T, class M> struct CovTab {
                 t.rd[l][RD_WS] = is_cross ? 0u : 0x3F800000u;
             }
             const int rc0 = R0 < D ? R0 : D - 1, cc0 = C0 < D ? C0 : D - 1;
-            t.rd[l][RD_NZ] = uint32_t((rc0 * D + cc0) * SZ);
+            t.rd[l][RD_NZ] = uint32_t((rc0 * D + cc0) * SZG);
             const bool writer = (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
             for (int i2 = 0; i2 < TR; ++i2)
                 for (int j2 = 0; j2 < TC; ++j2) {
@@ -350,7 +350,7 @@ template <class T, class M> struct CovTab {
                 const bool v = e < NAB;
                 const int rr = v ? tri_r(e) : 0, cc = v ? (e - rr * (rr + 1) / 2) : 0;
                 const int ar = NL + rr, ac = NL + cc;
-                t.rd[l][RD_ANZ + k] = uint32_t((ar * D + ac) * SZ);
+                t.rd[l][RD_ANZ + k] = uint32_t((ar * D + ac) * SZG);
                 t.wr[l][WR_AFF + k] = v ? uint32_t(LY::cv(ar, ac) * SZ) : sink;
                 t.wr[l][WR_AFF_RD + k] = uint32_t(LY::cv(ar, ac) * SZ);
             }
@@ -541,17 +541,16 @@ UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], T (&xp)[M::S
 }
 
 // One entry of the shaped process noise R without exec-masked regions (cf. process_noise_entry).
-template <class T, class M>
-UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const KArgs<T>& a, const ProcIn<T>& pin, int r,
-                                 int c) {
+template <class T, class M, class TS>
+UKFB_DEV T process_noise_entry16(const TS* Rn, const TS* Racc, const T* ROT, const ProcIn<T>& pin, int r, int c) {
     constexpr int D = M::D;
     T vacc = T(0);
     if (M::MODEL == 0) {
         // acceleration branch (PoseUKF.cpp:190-191): raw noise with block(6,6,3,3) = 2 acc.cov, prepared by
         // the host (ukf_batch.hip: rebuild_racc) whenever the noise or acc.cov changes
-        vacc = Racc[r * D + c];
+        vacc = T(Racc[r * D + c]);
     }
-    const T rn = Rn[r * D + c];
+    const T rn = T(Rn[r * D + c]);
     const int o = (r < 3 && c < 3) ? 0 : ((r >= 3 && r < 6 && c >= 3 && c < 6) ? 3 : -1);
     const int oo = o < 0 ? 0 : o;
     const int rr = (o < 0) ? 0 : (r - oo), cc = (o < 0) ? 0 : (c - oo);
@@ -560,7 +559,7 @@ UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const
     for (int m = 0; m < 3; ++m) {
         T tmp = T(0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tmp += ROT[rr * 3 + k] * Rn[(oo + k) * D + (oo + m)];
+        for (int k = 0; k < 3; ++k) tmp += ROT[rr * 3 + k] * T(Rn[(oo + k) * D + (oo + m)]);
         acc += tmp * ROT[cc * 3 + m];
     }
     const T val = (o >= 0) ? acc : rn;
@@ -570,11 +569,11 @@ UKFB_DEV T process_noise_entry16(const T* Rn, const T* Racc, const T* ROT, const
 }
 
 // The same for an entry OUTSIDE the two rotated 3x3 diagonal blocks (cross and affine blocks): no rotation.
-template <class T, class M> UKFB_DEV T plain_noise_entry16(const T* Rn, const T* Racc, const ProcIn<T>& pin, int r, int c) {
+template <class T, class M, class TS> UKFB_DEV T plain_noise_entry16(const TS* Rn, const TS* Racc, const ProcIn<T>& pin, int r, int c) {
     constexpr int D = M::D;
-    const T rn = Rn[r * D + c];
+    const T rn = T(Rn[r * D + c]);
     if (M::MODEL == 0) {
-        const T vacc = Racc[r * D + c];
+        const T vacc = T(Racc[r * D + c]);
         return pin.use_acc ? vacc : pin.dt * rn;
     }
     return (pin.dt * pin.dt) * rn;
@@ -642,8 +641,13 @@ template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
 // code: +3.0 % on the fp64 headline, +2.8 % fp32, +2.5 % config 4, +2 % OrientationState fp64 (same-box A/B, DESIGN.md
 // section 4.10).  The launcher picks it when all of that holds
 // (ukf_launch.inc.hpp); the arithmetic of a filter is the general kernel's, bit for bit (tests/test_gpu_plain_kernel.py).
-template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false, bool PLAINL = false>
-__global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(const KArgs<T> a) {
+// TS (storage type, default T): the type of every per-filter array and noise table in HBM.  TS = float with T = double is the
+// WIDE-ARITHMETIC mode of the fp32 engines (ukfb_config::wide_arithmetic): fp32 state and inputs in HBM, every instruction of
+// the cycle in fp64 (values widen on load and narrow on commit; the LDS slice is the fp64 one).  Why that and not a cheaper mix:
+// tests/study_f32_mixed.py / profiles/r04_f32_mixed_ab.txt -- over the bench's run length any stage left in fp32 (the SO(3)
+// maps or the factorisations / recombinations) keeps the OrientationState mean at 5e-4 ... 9e-4 from the fp64 algorithm.
+template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false, bool PLAINL = false, class TS = T>
+__global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(const KArgs<TS> a) {
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
     static_assert(!INDIRECT || (DO_PREDICT && DO_UPDATE && !MULTI), "indirect launches run the single fused cycle");
     static_assert(!PLAINL || (DO_PREDICT && DO_UPDATE && !INDIRECT), "plain launches run fused cycles, directly");
@@ -663,7 +667,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     const double* const a_dt = (MULTI || PLAINL) ? nullptr : a.dt;
     const uint8_t* const a_active = (MULTI || PLAINL) ? nullptr : a.active;
     const int32_t* const a_meas = PLAINL ? nullptr : a.meas;
-    const T gate_chi2_c = PLAINL ? T(-1) : a.gate_chi2;
+    const T gate_chi2_c = PLAINL ? T(-1) : T(a.gate_chi2);
     const bool status_accumulate_c = PLAINL ? false : (a.status_accumulate != 0);
     if constexpr (MULTI) {
         // multi-cycle launches are direct launches with one dt per cycle for every filter (checked by the host): no
@@ -708,20 +712,20 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         asm volatile("" : "+s"(b));
         return INDIRECT ? int64_t(0) : a.item0 + int64_t(group_of_block(b, gridDim.x)) * FPW;
     };
-    T* const mu_p = at_wg(a.mu, S);
-    T* const cov_p = at_wg(a.cov, PK);
+    TS* const mu_p = at_wg(a.mu, S);
+    TS* const cov_p = at_wg(a.cov, PK);
     uint32_t* const status_p = at_wg(a.status, 1);
     const uint8_t* const init_p = at_wg(a.initialised, 1);
     int64_t* const last_ts_p = at_wg(a.last_ts, 1);
-    const T* const in_a_p = at_wg(a.in_a, 3);
-    const T* const in_b_p = at_wg(a.in_b, 3);
+    const TS* const in_a_p = at_wg(a.in_a, 3);
+    const TS* const in_b_p = at_wg(a.in_b, 3);
     const int64_t* const ts_p = at_wg(a_ts, 1);
     const double* const dt_p = at_wg(a_dt, 1);
     const int32_t* const meas_p = at_wg(a_meas, 1);
     const uint8_t* const active_p = at_wg(a_active, 1);
-    const T* const z_p = at_wg(a.z, 3);
+    const TS* const z_p = at_wg(a.z, 3);
     const IDX q_stride = (!MULTI && a.q_uniform) ? 0 : 9;     // batch-uniform measurement covariance: every filter reads the same 9 scalars
-    const T* const Q_p = at_wg(a.Q, int64_t(q_stride));
+    const TS* const Q_p = at_wg(a.Q, int64_t(q_stride));
     T* base = reinterpret_cast<T*>(smem_raw) + g * LY::PF;
     T* Lc = base + LY::LC;
     T* TAB = base + LY::TNL;
@@ -767,9 +771,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
         const int e = l + G * t;
-        cov_l[t] = *at(static_cast<const T*>(cov_p), fc * PK + IDX((e < PK) ? e : (PK - 1)));
+        cov_l[t] = T(*at(static_cast<const TS*>(cov_p), fc * PK + IDX((e < PK) ? e : (PK - 1))));
     }
-    const T mu_l = *at(static_cast<const T*>(mu_p), fc * S + IDX((l < S) ? l : (S - 1)));
+    const T mu_l = T(*at(static_cast<const TS*>(mu_p), fc * S + IDX((l < S) ? l : (S - 1))));
     ProcIn<T> pin;
     // per-call inputs of one input slot (single-cycle launches: slot 0 = the arrays themselves)
     const auto load_inputs = [&](int slot, T (&ia)[3], T (&ib)[3], T& zq, int32_t& mid_slot) {
@@ -780,17 +784,17 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         }
         if constexpr (DO_PREDICT) {
             // latched inputs: the engine always passes both arrays (its own or the bound ones)
-            const T* pa = at(in_a_p + ((MULTI && (a.cyc_in & 1)) ? so * 3 : 0), fc * 3);
-            const T* pb = at(in_b_p + ((MULTI && (a.cyc_in & 2)) ? so * 3 : 0), fc * 3);
+            const TS* pa = at(in_a_p + ((MULTI && (a.cyc_in & 1)) ? so * 3 : 0), fc * 3);
+            const TS* pb = at(in_b_p + ((MULTI && (a.cyc_in & 2)) ? so * 3 : 0), fc * 3);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                ia[k] = pa[k];
-                ib[k] = pb[k];
+                ia[k] = T(pa[k]);
+                ib[k] = T(pb[k]);
             }
         }
         if constexpr (DO_UPDATE) {
-            const T* zp = (l < 3) ? at(z_p + so * 3, fi * 3 + IDX(l)) : at(Q_p + so * 9, fi * 9 + IDX((l < 12) ? (l - 3) : 0));
-            zq = *zp;
+            const TS* zp = (l < 3) ? at(z_p + so * 3, fi * 3 + IDX(l)) : at(Q_p + so * 9, fi * 9 + IDX((l < 12) ? (l - 3) : 0));
+            zq = T(*zp);
         }
     };
     T zq_l = T(0);
@@ -804,17 +808,17 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         if constexpr (PREFETCH) load_inputs(slot, pin.a, pin.w, zq_l, mid_l);
     } else {
         if constexpr (DO_PREDICT) {
-            const T* pa = at(in_a_p, fc * 3);
-            const T* pb = at(in_b_p, fc * 3);
+            const TS* pa = at(in_a_p, fc * 3);
+            const TS* pb = at(in_b_p, fc * 3);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                pin.a[k] = pa[k];
-                pin.w[k] = pb[k];
+                pin.a[k] = T(pa[k]);
+                pin.w[k] = T(pb[k]);
             }
         }
         if constexpr (DO_UPDATE) {
-            const T* zp = (l < 3) ? at(z_p, fi * 3 + IDX(l)) : at(Q_p, fi * q_stride + IDX((l < 12) ? (l - 3) : 0));
-            zq_l = *zp;
+            const TS* zp = (l < 3) ? at(z_p, fi * 3 + IDX(l)) : at(Q_p, fi * q_stride + IDX((l < 12) ? (l - 3) : 0));
+            zq_l = T(*zp);
         }
     }
 
@@ -915,11 +919,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
         }
         dtT = T(dt);
         pin.dt = dtT;
-        pin.ninv_tau_g = a.ninv_tau_g;
-        pin.ninv_tau_a = a.ninv_tau_a;
+        pin.ninv_tau_g = T(a.ninv_tau_g);
+        pin.ninv_tau_a = T(a.ninv_tau_a);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            pin.earth[k] = a.earth[k];
+            pin.earth[k] = T(a.earth[k]);
         }
         pin.use_acc = m_finite(pin.a[0]) && m_finite(pin.a[1]) && m_finite(pin.a[2]);
 #pragma unroll
@@ -1044,25 +1048,25 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 if constexpr (sizeof(T) == 8) {
                     // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) factor region:
                     // lane c sums component c over the 16 lanes and publishes the mean
-                    constexpr int TS = 18;   // row stride: b128 rows of lanes 0..NL-1 fall on distinct banks
-                    static_assert(NL * TS + NL <= D * LS, "transposition buffer must fit the factor region");
+                    constexpr int TBS = 18;   // row stride: b128 rows of lanes 0..NL-1 fall on distinct banks
+                    static_assert(NL * TBS + NL <= D * LS, "transposition buffer must fit the factor region");
                     T* TB = Lc;
 #pragma unroll
-                    for (int c = 0; c < NL; ++c) TB[c * TS + l] = loc[c];
+                    for (int c = 0; c < NL; ++c) TB[c * TBS + l] = loc[c];
                     wsync();
                     const int cl = (l < NL) ? l : (NL - 1);
                     T part[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) part[j] = TB[cl * TS + j];
+                    for (int j = 0; j < 16; ++j) part[j] = TB[cl * TBS + j];
 #pragma unroll
                     for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
                         for (int j = 0; j < w; ++j) part[j] += part[j + w];
-                    TB[NL * TS + cl] = part[0] * (T(1) / T(N));
+                    TB[NL * TBS + cl] = part[0] * (T(1) / T(N));
                     wsync();
 #pragma unroll
                     for (int c = 0; c < NL; ++c) {
-                        md[c] = TB[NL * TS + c];
+                        md[c] = TB[NL * TBS + c];
                         n2 += md[c] * md[c];
                     }
                 } else {
@@ -1124,7 +1128,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             T rpl[3] = {T(0), T(0), T(0)}, rml[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)};
             bool have_last = false;   // wave-uniform
             {
-                bool active = pc && n2 > a.mean_tol * a.mean_tol;   // (rows that commit nothing never keep the wavefront iterating)
+                bool active = pc && n2 > T(a.mean_tol) * T(a.mean_tol);   // (rows that commit nothing never keep the wavefront iterating)
                 int it = 0;
                 if (active && ++it >= a.mean_max_it) { active = false; conv = false; }
 #if defined(UKFB_COUNTS)
@@ -1158,7 +1162,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) qr[k] = active ? nq[k] : qr[k];
-                    const bool more = m2 > a.mean_tol * a.mean_tol;
+                    const bool more = m2 > T(a.mean_tol) * T(a.mean_tol);
                     const bool capped = more && (it + 1 >= a.mean_max_it);
                     it += (active && more) ? 1 : 0;
                     conv = conv && !(active && capped);
@@ -1171,11 +1175,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             }
             UKFB_MARK("p_delta_r");
             // lane constants of the covariance phase (CovTab, Pose kernels), requested here so that they have arrived when it starts
-            uint32_t ctr[CovTab<T, M>::NRD];
+            uint32_t ctr[CovTab<T, M, TS>::NRD];
             if constexpr (M::MODEL == 0) {
-                const uint32_t* rrow = CovTab<T, M>::tabs.rd[l];
+                const uint32_t* rrow = CovTab<T, M, TS>::tabs.rd[l];
 #pragma unroll
-                for (int k = 0; k < CovTab<T, M>::NRD; ++k) ctr[k] = rrow[k];
+                for (int k = 0; k < CovTab<T, M, TS>::NRD; ++k) ctr[k] = rrow[k];
             }
             {   // rotation deltas to the final mean; quaternion of the mean.  The loop's last trip took the logarithms
                 // against the reference BEFORE its (sub-tolerance) move al: re-base them to first order in al, exact in
@@ -1223,7 +1227,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             // twice the table loads, and with them config 4 measured -1.4 %.
             constexpr bool LANE_TABLES = (M::MODEL == 0);
             if constexpr (LANE_TABLES) {
-                using CT = CovTab<T, M>;
+                using CT = CovTab<T, M, TS>;
                 static_assert(10 + TR <= D && 3 + TC <= NL, "Pose tile table: every tile entry is a valid (row, column)");
                 constexpr int AEL = CT::AEL;   // affine block entries per lane
                 unsigned char* const wbase = reinterpret_cast<unsigned char*>(base);
@@ -1237,11 +1241,11 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     for (int k = 0; k < CT::WR_AFF_RD + AEL; ++k) ctw[k] = wrow[k];
                 }
                 const int64_t wgn = wg0_again() * a.Rn_stride;
-                const T* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
-                const T* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
-                // element imm behind byte offset off of the table p
-                const auto at_off = [](const T* p, uint32_t off, int imm) {
-                    return reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(p) + off)[imm];
+                const TS* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
+                const TS* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
+                // element imm behind byte offset off of the (HBM) table p
+                const auto at_off = [](const TS* p, uint32_t off, int imm) {
+                    return T(reinterpret_cast<const TS*>(reinterpret_cast<const unsigned char*>(p) + off)[imm]);
                 };
                 // plain (un-rotated) noise entry (cf. plain_noise_entry16)
                 const auto plain_off = [&](uint32_t off, int imm) {
@@ -1271,7 +1275,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     for (int t = 0; t < 2; ++t) {
                         const bool v = l + G * t < NL * (NL + 1) / 2;
                         const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
-                        NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                        NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, pin, r, c);
                     }
                     const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
                     const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
@@ -1340,8 +1344,8 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 static_assert(!TILES_INSIDE || (10 + TR <= D && 3 + TC <= NL), "Pose tile table");
                 constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
                 const int64_t wgn = wg0_again() * a.Rn_stride;
-                const T* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
-                const T* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
+                const TS* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
+                const TS* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
                 const bool all_acc = NZ_EARLY && wave_all(pin.use_acc);
                 // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
                 // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
@@ -1368,10 +1372,10 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                             for (int j2 = 0; j2 < TC; ++j2) {
                                 const int r = R0 + i2, c = C0 + j2;
                                 const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                                nz[i2][j2] = Ra[rc * D + cc];
+                                nz[i2][j2] = T(Ra[rc * D + cc]);
                             }
 #pragma unroll
-                        for (int t = 0; t < AEL; ++t) anz[t] = Ra[ar[t] * D + ac[t]];
+                        for (int t = 0; t < AEL; ++t) anz[t] = T(Ra[ar[t] * D + ac[t]]);
                     } else {
                         // Rotated noise (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85): only the two 3x3 diagonal blocks of
                         // the nonlinear 6x6 block are rotated.  Its 21 entries are evaluated ONCE per filter, at most two
@@ -1384,7 +1388,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                             const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
                             // (isotropic blocks, noise_plain: the table entry itself, no rotation and no rotation matrix)
                             const T ne = (M::MODEL != 0 && noise_plain) ? plain_noise_entry16<T, M>(Rn, Ra, pin, r, c)
-                                                                        : process_noise_entry16<T, M>(Rn, Ra, ROT, a, pin, r, c);
+                                                                        : process_noise_entry16<T, M>(Rn, Ra, ROT, pin, r, c);
                             NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = ne;
                         }
                         if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
@@ -1646,7 +1650,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                         quat_mul(zref, e, nq);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) zref[k] = active ? nq[k] : zref[k];
-                        const bool more = m2 > a.mean_tol * a.mean_tol;
+                        const bool more = m2 > T(a.mean_tol) * T(a.mean_tol);
                         const bool capped = more && (it + 1 >= a.mean_max_it);
                         it += (active && more) ? 1 : 0;
                         zc = zc && !(active && capped);
@@ -1925,8 +1929,8 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     // =========================================================================== commit
     const uint32_t st = st_all;
     const int64_t wgc = wg0_again();
-    T* const cov_c = a.cov + wgc * PK;
-    T* const mu_c = a.mu + wgc * S;
+    TS* const cov_c = a.cov + wgc * PK;
+    TS* const mu_c = a.mu + wgc * S;
     uint32_t* const status_c = a.status + wgc;
     // (the store offsets are the prologue's load offsets; formed again from an opaque copy of the row's index, or the
     // compiler keeps all of them in registers across the whole kernel)
@@ -1936,9 +1940,9 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const int e = l + G * t;
-            if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = PKS[e];
+            if (e < PK) *at(cov_c, fcc * PK + IDX(e)) = TS(PKS[e]);
         }
-        if (l < S) *at(mu_c, fcc * S + IDX(l)) = MUS[l];
+        if (l < S) *at(mu_c, fcc * S + IDX(l)) = TS(MUS[l]);
     }
     if (fvalid && l == 0) *at(status_c, fcc) = status_accumulate_c ? (*at(status_c, fcc) | st) : st;
 }

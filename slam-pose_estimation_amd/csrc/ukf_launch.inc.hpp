@@ -41,7 +41,8 @@ template <class T, class M, int G> static int launch_g(ukfb_engine* e, const Lau
 // Diagnostic builds (tools/phase_stamps.py, tools/trip_counts.py): every launch is synchronous; the per-marker s_memtime stamps of
 // all wavefronts are reduced to mean cycles between consecutive executed markers and appended to the file
 // named by UKFB_STAMP_OUT (one line per launch: kernel name, then marker_index:mean_delta pairs).
-template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds, bool plain) {
+template <class T, class M, class TC = T> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds, bool plain) {
+    using MC = typename M::template rebind<TC>;   // (stamped builds: the kernel's own manifold type)
     static unsigned long long* dbuf = nullptr;
     static size_t dcap = 0;
     const size_t need = size_t(grid) * UKFB_MAX_STAMPS;
@@ -60,19 +61,19 @@ template <class T, class M> static int launch_row16_stamped(ukfb_engine* e, cons
     }
 #endif
     if (args.fidx)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, true, false, T>), gd, bd, lds, main_stream(e), args);
     else if (r.cycles > 0 && plain)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, true, T>), gd, bd, lds, main_stream(e), args);
     else if (r.cycles > 0)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, false, T>), gd, bd, lds, main_stream(e), args);
     else if (plain)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, true, T>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, false, false, false, false, T>), gd, bd, lds, main_stream(e), args);
     else
-        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, false, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
     if (hipStreamSynchronize(main_stream(e)) != hipSuccess) return UKFB_ERR_HIP;
     const char* path = getenv("UKFB_STAMP_OUT");
     if (!path) return UKFB_OK;
@@ -143,13 +144,16 @@ static int64_t split_max_filters() {
     return v;
 }
 
-// tuned kernel: one DPP row per filter (ukf_kernel16.hpp)
-template <class T, class M> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
+// tuned kernel: one DPP row per filter (ukf_kernel16.hpp).  T: the engine's precision = the type of every array in HBM;
+// TC: the type the kernel computes in (TC = double with T = float: the wide-arithmetic mode of the fp32 engines, whose LDS slice
+// and register budget are the fp64 kernel's).
+template <class T, class M, class TC = T> static int launch_row16(ukfb_engine* e, const LaunchReq& r, const KArgs<T>& args) {
+    using MC = typename M::template rebind<TC>;
     constexpr int FPW = 4;
     const int64_t grid = (args.n + FPW - 1) / FPW;
     // (UKFB_LDS_PAD_BYTES in the environment requests that much more dynamic LDS per workgroup: occupancy experiments only)
     static const int lds_pad = [] { const char* s = std::getenv("UKFB_LDS_PAD_BYTES"); return s ? std::atoi(s) : 0; }();
-    const int lds = FPW * lds_bytes_per_filter16<T, M>() + lds_pad;
+    const int lds = FPW * lds_bytes_per_filter16<TC, MC>() + lds_pad;
     const bool multi = r.cycles > 0;   // ukfb_cycle_multi_dev: fused cycles only (checked by the caller)
     // the plain instantiation (ukf_kernel16<..., PLAINL>): everything the kernel may then take as a compile-time fact
     const char* const plain_env = std::getenv("UKFB_NO_PLAIN_KERNEL");   // (A/B and tests: =1 keeps the general kernel; read per launch)
@@ -159,7 +163,7 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
                        (M::MODEL != 0 ? args.meas_uniform == 9
                                       : (args.meas_uniform == 0 || args.meas_uniform == 4 || args.meas_uniform == 8));
     const char* mode = multi ? (plain ? "multicycle-plain" : "multicycle") : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : (plain ? "cycle-plain" : "cycle")) : "predict") : "update");
-    e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : "f32") + "," +
+    e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : (sizeof(TC) == 8 ? "f32-wide" : "f32")) + "," +
                      (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
     e->last_lds = lds;
     e->last_fpw = FPW;
@@ -167,7 +171,7 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
     if (grid == 0) return UKFB_OK;
     const dim3 gd((unsigned)grid), bd(64);
 #if defined(UKFB_STAMPS) || defined(UKFB_COUNTS)
-    return launch_row16_stamped<T, M>(e, r, args, grid, lds, plain);
+    return launch_row16_stamped<T, M, TC>(e, r, args, grid, lds, plain);
 #endif
     // Two half launches on two streams (engines that own their stream, direct launches of SPLIT_MIN <= n < SPLIT_MAX filters):
     // launch k + 1's first half follows launch k's first half on `stream`, its second half follows launch k's second half on
@@ -185,12 +189,12 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
             hipLaunchKernelGGL(kern, g1, bd, lds, sa, h1);
             hipLaunchKernelGGL(kern, g2, bd, lds, sb, h2);
         };
-        if (multi && plain) go(ukf_kernel16<T, M, true, true, true, false, true>);
-        else if (multi) go(ukf_kernel16<T, M, true, true, true>);
-        else if (plain) go(ukf_kernel16<T, M, true, true, false, false, true>);
-        else if (r.do_predict && r.do_update) go(ukf_kernel16<T, M, true, true>);
-        else if (r.do_predict) go(ukf_kernel16<T, M, true, false>);
-        else go(ukf_kernel16<T, M, false, true>);
+        if (multi && plain) go(ukf_kernel16<TC, MC, true, true, true, false, true, T>);
+        else if (multi) go(ukf_kernel16<TC, MC, true, true, true, false, false, T>);
+        else if (plain) go(ukf_kernel16<TC, MC, true, true, false, false, true, T>);
+        else if (r.do_predict && r.do_update) go(ukf_kernel16<TC, MC, true, true, false, false, false, T>);
+        else if (r.do_predict) go(ukf_kernel16<TC, MC, true, false, false, false, false, T>);
+        else go(ukf_kernel16<TC, MC, false, true, false, false, false, T>);
         e->split_pending = true;
         const hipError_t serr = hipGetLastError();
         if (serr != hipSuccess) {
@@ -204,19 +208,19 @@ template <class T, class M> static int launch_row16(ukfb_engine* e, const Launch
             set_error("indirect launches run the single fused cycle", hipErrorInvalidValue);
             return UKFB_ERR_INVALID_ARG;
         }
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, true, false, T>), gd, bd, lds, main_stream(e), args);
     } else if (multi && plain)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, true, T>), gd, bd, lds, main_stream(e), args);
     else if (multi)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, false, T>), gd, bd, lds, main_stream(e), args);
     else if (plain)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true, false, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, true, T>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
     else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel16<T, M, true, false>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, false, false, false, false, T>), gd, bd, lds, main_stream(e), args);
     else
-        hipLaunchKernelGGL((ukf_kernel16<T, M, false, true>), gd, bd, lds, main_stream(e), args);
+        hipLaunchKernelGGL((ukf_kernel16<TC, MC, false, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("kernel launch", err);
@@ -280,6 +284,7 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
     // instantiations need more than 256 VGPRs and the compiler parks the excess in AGPRs -- live-range-split copies of the
     // kind DESIGN.md 4.5 distrusts with this toolchain.  -DUKFB_GENERIC_F64=1 (make GENERIC_F64=1) builds them for
     // diagnostics; ukfb_set_config refuses the setting otherwise (ukfb_layout_supported tells).
+#if !defined(UKFB_LAUNCH_WIDE)
     if constexpr (sizeof(T) == 4 || UKFB_GENERIC_F64 != 0) {
         switch (e->cfg.lanes_per_filter) {
             case 64: return launch_g<T, M, 64>(e, r, a);
@@ -287,7 +292,12 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
             default: break;
         }
     }
+#endif
+#if defined(UKFB_LAUNCH_WIDE)
+    return launch_row16<T, M, double>(e, r, a);
+#else
     return launch_row16<T, M>(e, r, a);
+#endif
 }
 
 }  // namespace ukfb

@@ -56,7 +56,7 @@ EXPORTS = [
     "ukfb_group_cycle", "ukfb_group_pose_bind_acceleration_dev", "ukfb_group_orient_bind_inputs_dev",
     "ukfb_group_cycle_dev", "ukfb_group_cycle_multi_dev", "ukfb_group_cycle_mixed_dev", "ukfb_group_cycle_timestamps",
     "ukfb_group_process_events", "ukfb_group_sync", "ukfb_group_timer_begin",
-    "ukfb_group_timer_end", "ukfb_group_gather_means",
+    "ukfb_group_timer_end", "ukfb_group_gather_means", "ukfb_group_last_gather_exchange",
 ]
 BODY_STATE_SCALARS = 49
 
@@ -64,7 +64,7 @@ BODY_STATE_SCALARS = 49
 class Config(C.Structure):
     _fields_ = [("mean_tol", C.c_double), ("mean_max_iter", C.c_int32), ("gate_chi2", C.c_double),
                 ("min_time_delta", C.c_double), ("max_time_delta", C.c_double), ("lanes_per_filter", C.c_int32),
-                ("bucket_models", C.c_int32), ("split_streams", C.c_int32)]
+                ("bucket_models", C.c_int32), ("split_streams", C.c_int32), ("wide_arithmetic", C.c_int32)]
 
 
 class UkfbError(RuntimeError):
@@ -651,3 +651,7 @@ class UKFGroup:
     def gather_means(self, out_devs):
         """RCCL all-gather of the means: out_devs[r] = device buffer [total][S] (engine precision) on shard r's device."""
         _chk(self._lib.ukfb_group_gather_means(self._g, self._ptrs(out_devs)), "ukfb_group_gather_means")
+
+    def last_gather_exchange(self) -> str:
+        """which exchange the last gather_means used: "rccl" (one shard per device) or "copies" (shards sharing a device)"""
+        return {0: "none", 1: "rccl", 2: "copies"}.get(int(self._lib.ukfb_group_last_gather_exchange(self._g)), "?")

@@ -39,8 +39,9 @@ def _dist(a, b):
     return float(np.max(np.abs(a - b)))
 
 
-def run(spe, capi, workload="pose", n=2048, cycles=600, checkpoints=CHECKPOINTS, threads=8, with_f64_engine=False):
-    """Returns a list of rows {cycle, gpu_o64: (mu, cov), o32_o64: (mu, cov), gpu_o32: (mu, cov)[, gpu64_o64: (mu, cov)]}."""
+def run(spe, capi, workload="pose", n=2048, cycles=600, checkpoints=CHECKPOINTS, threads=8, with_f64_engine=False, wide=False):
+    """wide: the fp32 engine runs with ukfb_config.wide_arithmetic = 1 (fp32 arrays, fp64 arithmetic).
+    Returns a list of rows {cycle, gpu_o64: (mu, cov), o32_o64: (mu, cov), gpu_o32: (mu, cov)[, gpu64_o64: (mu, cov)]}."""
     import torch
     sy = spe.synth
     orient = workload == "orient"
@@ -52,7 +53,8 @@ def run(spe, capi, workload="pose", n=2048, cycles=600, checkpoints=CHECKPOINTS,
         Rn = sy.orient_process_noise()
 
         def make(prec):
-            e = spe.BatchOrientationUKF(n, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec)
+            e = spe.BatchOrientationUKF(n, sy.ORIENT_TAU, sy.ORIENT_TAU, sy.ORIENT_LATITUDE, precision=prec,
+                                        **({"wide_arithmetic": 1} if (wide and prec == spe.F32) else {}))
             e.set_process_noise(Rn)
             return e
     else:
@@ -63,7 +65,7 @@ def run(spe, capi, workload="pose", n=2048, cycles=600, checkpoints=CHECKPOINTS,
         acc_cov = 0.01 * np.eye(3)
 
         def make(prec):
-            e = spe.BatchPoseUKF(n, precision=prec)
+            e = spe.BatchPoseUKF(n, precision=prec, **({"wide_arithmetic": 1} if (wide and prec == spe.F32) else {}))
             e.set_acceleration(None, acc_cov)
             return e
     mu, cov = _f32(mu), _f32(cov)

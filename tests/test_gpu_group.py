@@ -2,8 +2,9 @@
 
 Independence basis: every filter of the reference owns its own ukf object (/root/reference/src/UnscentedKalmanFilter.hpp:150),
 so contiguous shards need no collective on the data path; the one exchange is the RCCL all-gather of the means.  A gpurun
-box has ONE GPU: the N > 1 data path is covered by two shards on device 0 (everything but the gather, which RCCL refuses
-for two ranks on one device), the collective by a one-device group (a communicator of one rank)."""
+box has ONE GPU: the N > 1 data path is covered by 2, 3 and 8 shards on device 0 -- incl. the gather's staging and ragged
+compaction, with peer copies standing in for the exchange RCCL refuses two ranks on one device -- and the RCCL collective
+itself by a one-device group (a communicator of one rank)."""
 import numpy as np
 import pytest
 
@@ -55,12 +56,41 @@ def test_two_shards_on_one_device_equal_the_unsharded_batch(spe, prec):
     lo = grp.shards[1]["first"] - 5
     ms, cs, _ = grp.state(lo, 11)
     assert np.array_equal(ms, m1[lo:lo + 11]) and np.array_equal(cs, c1[lo:lo + 11])
-    # the collective needs one rank per device
-    out = [torch.empty((n, 13), dtype=tdt, device="cuda") for _ in range(2)]
-    with pytest.raises(spe.UkfbError) as ei:
-        grp.gather_means(out)
-    assert "share a device" in str(ei.value)
+    # shards that share a device gather by peer copies (RCCL wants one rank per device): same staging, same ragged compaction
+    out = [torch.full((n, 13), float("nan"), dtype=tdt, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    grp.gather_means(out)
+    grp.sync()
+    assert grp.last_gather_exchange() == "copies"
+    for o in out:
+        assert np.array_equal(o.double().cpu().numpy(), m1)
     grp.close(); one.close()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shards,n", [(2, 101), (3, 1000), (8, 4099), (8, 9)])
+def test_ragged_gather_of_n_shards_on_one_device(spe, prec, shards, n):
+    """The N > 1 gather path of ukfb_group_gather_means -- padded staging, exchange, compaction of ragged shards (down to 9 filters
+    over 8 shards: one shard of two, seven of one) -- on one device: every shard's output buffer holds the means of all filters in batch
+    order, bit-equal to ukfb_group_get_state, also after further cycles (the staging buffers are reused)."""
+    import torch
+    mu, cov, ring, tdt = _inputs(spe, n, prec)
+    grp = spe.UKFGroup(spe.MODEL_POSE, prec, n, [0] * shards)
+    counts = [s["count"] for s in grp.shards]
+    assert sum(counts) == n and max(counts) - min(counts) <= 1
+    grp.initialize(mu, cov)
+    grp.set_acceleration(ring[0][0], 0.01 * np.eye(3))
+    out = [torch.full((n, 13), float("nan"), dtype=tdt, device="cuda") for _ in range(shards)]
+    torch.cuda.synchronize()
+    for k in range(2):
+        grp.cycle(0.01, spe.MEAS_POS3, ring[k][1], ring[k][2])
+        grp.gather_means(out)
+        grp.sync()
+        mg, _, _ = grp.state()
+        assert grp.last_gather_exchange() == "copies" and np.isfinite(mg).all()
+        for o in out:
+            assert np.array_equal(o.double().cpu().numpy(), mg)
+    grp.close()
 
 
 @pytest.mark.parametrize("prec", [0, 1])

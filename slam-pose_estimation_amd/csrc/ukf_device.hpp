@@ -47,6 +47,31 @@ enum { QX = 0, QY = 1, QZ = 2, QW = 3 };
 // about thirty times (every exp / log asks whether any lane needs its wide-angle path).
 UKFB_DEV bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 UKFB_DEV bool wave_all(bool b) { return __builtin_amdgcn_ballot_w64(b) == __builtin_amdgcn_ballot_w64(true); }
+// Lane masks straight from ONE compare (active lanes only, like a ballot).  Where the compared bool also steers selects or an
+// exec-masked region, the compiler lowers ballot(b) by materialising b in a VGPR and comparing it again (v_cndmask 0/1 +
+// v_cmp_ne: two 4-cycle instructions per vote, ~25 votes on the hot path); with the mask in hand the vote is a scalar test and
+// the selects take the SGPR pair through inverse_ballot.  lanes_not_le: !(x <= bound), true for NaN as well.
+UKFB_DEV unsigned long long lanes_not_le(double x, double bound) {
+    unsigned long long m;
+    asm("v_cmp_nge_f64_e64 %0, %1, %2" : "=s"(m) : "s"(bound), "v"(x));
+    return m;
+}
+UKFB_DEV unsigned long long lanes_not_le(float x, float bound) {
+    unsigned long long m;
+    asm("v_cmp_nge_f32_e64 %0, %1, %2" : "=s"(m) : "s"(bound), "v"(x));
+    return m;
+}
+UKFB_DEV unsigned long long lanes_gt(double x, double bound) {
+    unsigned long long m;
+    asm("v_cmp_lt_f64_e64 %0, %1, %2" : "=s"(m) : "s"(bound), "v"(x));
+    return m;
+}
+UKFB_DEV unsigned long long lanes_gt(float x, float bound) {
+    unsigned long long m;
+    asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "s"(bound), "v"(x));
+    return m;
+}
+UKFB_DEV bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // ---------------------------------------------------------------------------------------------
 // Fast, division-free primitives for the tuned kernel (ukf_kernel16.hpp).  All are accurate to a
@@ -210,10 +235,11 @@ template <class T> UKFB_DEV void so3_log_fast(const T (&q)[4], T (&r)[3]) {
     const T rw = fast_rcp(w);
     const T u = v2 * rw * rw;
     T s = T(2) * rw * poly_atan_ratio(u);
-    const bool big = !(u <= Poly<T>::U_SMALL);
+    const unsigned long long bigm = lanes_not_le(u, Poly<T>::U_SMALL);
     UKFB_DBG_COUNT(DBG_LOG);
-    if (wave_any(big)) {
+    if (bigm != 0ull) {
         UKFB_DBG_COUNT(DBG_LOG_BIG);
+        const bool big = lane_of(bigm);
         const T n2 = fma(w, w, v2);
         const T n = n2 * fast_rsqrt(n2);
         const T r1 = fast_rcp(m_abs(w) + n);
@@ -243,10 +269,11 @@ template <class T> UKFB_DEV void so3_log_fast_n(const T (&q)[4], T nrm, T (&r)[3
     const T r1 = fast_rcp(w + nrm);
     const T t1 = v2 * r1 * r1;                           // tan^2(phi/2)
     T s = T(4) * r1 * poly_atan_ratio(t1);
-    const bool big = !(t1 <= Poly<T>::U_SMALL);          // also w + |q| <= 0 (angle >= pi) and NaN
+    const unsigned long long bigm = lanes_not_le(t1, Poly<T>::U_SMALL);   // also w + |q| <= 0 (angle >= pi) and NaN
     UKFB_DBG_COUNT(DBG_LOGN);
-    if (wave_any(big)) {
+    if (bigm != 0ull) {
         UKFB_DBG_COUNT(DBG_LOGN_BIG);
+        const bool big = lane_of(bigm);
         const T r1b = fast_rcp(m_abs(w) + nrm);
         const T t1b = v2 * r1b * r1b;                    // tan^2(phi/2) <= 1 with phi = atan(|vec| / |w|)
         const T q2 = T(1) + t1b;
@@ -259,6 +286,43 @@ template <class T> UKFB_DEV void so3_log_fast_n(const T (&q)[4], T nrm, T (&r)[3
         s = big ? ((w < T(0)) ? -sb : sb) : s;
     }
     r[0] = s * q[0]; r[1] = s * q[1]; r[2] = s * q[2];
+}
+
+// Two logarithms at once (the + and - sigma point of a lane against the same reference): the same arithmetic as two calls of
+// so3_log_fast_n, but ONE wave-uniform vote for the wide-angle path of both, so that the common path is straight-line code with
+// two independent dependency chains for the scheduler to interleave (a branch between the two calls keeps them apart; the
+// Horner chain of one logarithm alone leaves the fp64 pipeline waiting on itself).
+template <class T> UKFB_DEV void so3_log_fast_n2(const T (&qa)[4], const T (&qb)[4], T nrm, T (&ra)[3], T (&rb)[3]) {
+    const T v2a = qa[0] * qa[0] + qa[1] * qa[1] + qa[2] * qa[2];
+    const T v2b = qb[0] * qb[0] + qb[1] * qb[1] + qb[2] * qb[2];
+    const T r1a = fast_rcp(qa[3] + nrm), r1b = fast_rcp(qb[3] + nrm);
+    const T t1a = v2a * r1a * r1a, t1b = v2b * r1b * r1b;
+    T sa = T(4) * r1a * poly_atan_ratio(t1a);
+    T sb = T(4) * r1b * poly_atan_ratio(t1b);
+    const unsigned long long biga = lanes_not_le(t1a, Poly<T>::U_SMALL), bigb = lanes_not_le(t1b, Poly<T>::U_SMALL);
+    UKFB_DBG_COUNT(DBG_LOGN);
+    UKFB_DBG_COUNT(DBG_LOGN);
+    if ((biga | bigb) != 0ull) {
+        UKFB_DBG_COUNT(DBG_LOGN_BIG);
+        UKFB_DBG_COUNT(DBG_LOGN_BIG);
+        const auto wide = [&](const T v2, const T w) {
+            const T r1w = fast_rcp(m_abs(w) + nrm);
+            const T t1w = v2 * r1w * r1w;
+            const T q2 = T(1) + t1w;
+            const T r2 = fast_rcp(T(1) + q2 * fast_rsqrt(q2));
+            const T t2 = t1w * r2 * r2;
+            const T q3 = T(1) + t2;
+            const T r3 = fast_rcp(T(1) + q3 * fast_rsqrt(q3));
+            const T t3 = t2 * r3 * r3;
+            const T sw = T(16) * (r1w * r2) * r3 * poly_atan_ratio(t3);
+            return (w < T(0)) ? -sw : sw;
+        };
+        const T wa = wide(v2a, qa[3]), wb = wide(v2b, qb[3]);
+        sa = lane_of(biga) ? wa : sa;
+        sb = lane_of(bigb) ? wb : sb;
+    }
+    ra[0] = sa * qa[0]; ra[1] = sa * qa[1]; ra[2] = sa * qa[2];
+    rb[0] = sb * qb[0]; rb[1] = sb * qb[1]; rb[2] = sb * qb[2];
 }
 
 // Rotation delta after a SMALL move of the reference: with d = log(conj(r) q) already known and r' = r exp(a),

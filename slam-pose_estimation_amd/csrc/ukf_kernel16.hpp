@@ -90,10 +90,9 @@ template <int C> UKFB_DEV float rcp_bcast(float v) {
 }
 // (fp64: the assembler accepts v_rcp_f64_dpp, the hardware does not broadcast for it -- every pivot came out wrong; the move stays)
 template <int C> UKFB_DEV double rcp_bcast(double v) { return fast_rcp(row_bcast<C>(v)); }
-// true on every lane of a 16-lane row iff v holds on all 16 of them: one compare, the reduction is scalar (and-fold of the ballot
+// true on every lane of a 16-lane row iff the lane mask b holds on all 16 of them: the reduction is scalar (and-fold of the mask
 // inside each 16-bit field, widened back to a lane mask); needs all 64 lanes active
-UKFB_DEV bool row_all(bool v) {
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+UKFB_DEV bool row_all(unsigned long long b) {
     unsigned long long t = b & (b >> 8);
     t &= t >> 4;
     t &= t >> 2;
@@ -443,8 +442,9 @@ template <class T, int D, int LS, int KS = D, int PUB = KS> UKFB_DEV T chol16(T 
     const int lc = (l < PUB) ? l : (PUB - 1);
     const T pv = Lc[lc * LS + lc];
     // pivot k is final once step k - 1 has run and is what column k publishes on its diagonal: lane l < PUB checks its own,
-    // one compare for all of them instead of one broadcast + compare per step
-    ok = good && row_all((l >= PUB) || (pv > T(0)));
+    // one compare for all of them instead of one broadcast + compare per step (lanes >= PUB of every row: a constant mask)
+    constexpr unsigned long long NO_PIVOT = ((0xFFFFull << PUB) & 0xFFFFull) * 0x0001000100010001ull;
+    ok = good && row_all(NO_PIVOT | lanes_gt(pv, T(0)));
     return fast_rsqrt(pv);   // this lane's column scale 1/sqrt(pivot_l) (lanes >= PUB: the last published one)
 }
 
@@ -474,6 +474,15 @@ template <class T> UKFB_DEV void rot_minus(const T (&qx)[4], const T (&qy)[4], T
     T d[4];
     quat_mul(oc, qx, d);
     so3_log_fast(d, r);
+}
+
+// log(conj(y) * xa), log(conj(y) * xb) with the norm of the products known: both at once (so3_log_fast_n2)
+template <class T> UKFB_DEV void rot_minus_n2(const T (&qxa)[4], const T (&qxb)[4], const T (&qy)[4], T nrm, T (&ra)[3], T (&rb)[3]) {
+    const T oc[4] = {-qy[0], -qy[1], -qy[2], qy[3]};
+    T da[4], db[4];
+    quat_mul(oc, qxa, da);
+    quat_mul(oc, qxb, db);
+    so3_log_fast_n2(da, db, nrm, ra, rb);
 }
 
 // the same with the norm of conj(y) * x known (see so3_log_fast_n)
@@ -520,6 +529,19 @@ template <class T> UKFB_DEV void process_fast(OrientM<T>*, T (&x)[14], const Pro
     }
 }
 
+// q * e and q * conj(e) for e = (u, c): A = c q and B = q * (u, 0) serve both, A + B and A - B (24 operations instead of 32)
+template <class T> UKFB_DEV void quat_mul_pm(const T (&q)[4], const T (&e)[4], T (&rp)[4], T (&rm)[4]) {
+    const T c = e[3];
+    const T bx = q[QW] * e[0] + q[QY] * e[2] - q[QZ] * e[1];
+    const T by = q[QW] * e[1] + q[QZ] * e[0] - q[QX] * e[2];
+    const T bz = q[QW] * e[2] + q[QX] * e[1] - q[QY] * e[0];
+    const T bw = -(q[QX] * e[0] + q[QY] * e[1] + q[QZ] * e[2]);
+    rp[QX] = fma(c, q[QX], bx); rm[QX] = fma(c, q[QX], -bx);
+    rp[QY] = fma(c, q[QY], by); rm[QY] = fma(c, q[QY], -by);
+    rp[QZ] = fma(c, q[QZ], bz); rm[QZ] = fma(c, q[QZ], -bz);
+    rp[QW] = fma(c, q[QW], bw); rm[QW] = fma(c, q[QW], -bw);
+}
+
 // sigma pair mu [+] (+col), mu [+] (-col): one exp serves both points, exp(-v) = conj(exp(v))
 template <class T, class M>
 UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], T (&xp)[M::S], T (&xm)[M::S]) {
@@ -533,9 +555,7 @@ UKFB_DEV void sigma_pair(const T (&mu)[M::S], const T (&col)[M::D], T (&xp)[M::S
     const T v[3] = {col[RT], col[RT + 1], col[RT + 2]};
     T ep[4], rp[4], rm[4];
     so3_exp_fast(v, T(1), ep);
-    const T em[4] = {-ep[0], -ep[1], -ep[2], ep[3]};
-    quat_mul(q, ep, rp);
-    quat_mul(q, em, rm);
+    quat_mul_pm(q, ep, rp, rm);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { xp[Q + k] = rp[k]; xm[Q + k] = rm[k]; }
 }
@@ -646,11 +666,18 @@ template <class P> UKFB_DEV P* at32(P* base, uint32_t idx) {
 // the cycle in fp64 (values widen on load and narrow on commit; the LDS slice is the fp64 one).  Why that and not a cheaper mix:
 // tests/study_f32_mixed.py / profiles/r04_f32_mixed_ab.txt -- over the bench's run length any stage left in fp32 (the SO(3)
 // maps or the factorisations / recombinations) keeps the OrientationState mean at 5e-4 ... 9e-4 from the fp64 algorithm.
-template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false, bool PLAINL = false, class TS = T>
+// PLAIN is a level: 0 = the general kernel; 1 = STREAMS ONLY (round 4): no per-filter timestamps / time steps / activity flags,
+// accept-any gate, fresh status word -- but per-filter model ids are allowed (model-class buckets of a mixed stream, any uniform
+// model); 2 = the plain launch described above (level 1 + one full-3-vector model for the launch).  Levels 1 and 2 also exist
+// for prediction-only and update-only launches (callers that keep the reference's two calls, UnscentedKalmanFilter.hpp:107-125
+// then PoseUKF.cpp:112-173) and level 1 for indirect launches over a bucketed filter list.
+template <class T, class M, bool DO_PREDICT, bool DO_UPDATE, bool MULTI = false, bool INDIRECT = false, int PLAIN = 0, class TS = T>
 __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(const KArgs<TS> a) {
+    constexpr bool STREAMS_ONLY = PLAIN >= 1, PLAINL = PLAIN == 2;
     static_assert(!MULTI || (DO_PREDICT && DO_UPDATE), "multi-cycle launches run the fused cycle");
     static_assert(!INDIRECT || (DO_PREDICT && DO_UPDATE && !MULTI), "indirect launches run the single fused cycle");
-    static_assert(!PLAINL || (DO_PREDICT && DO_UPDATE && !INDIRECT), "plain launches run fused cycles, directly");
+    static_assert(!PLAINL || !INDIRECT, "a plain launch is direct (one model for every filter)");
+    static_assert(PLAIN >= 0 && PLAIN <= 2, "plain level");
     constexpr int S = M::S, D = M::D, N = 2 * D + 1, PK = D * (D + 1) / 2;
     using LY = Layout16<T, M>;
     constexpr int LS = LY::LS, Q = MT<M>::Q, RT = MT<M>::RT, TR = MT<M>::TR, TC = MT<M>::TC;
@@ -663,12 +690,12 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
     // a kernel argument: the loads of an argument inside the cycle loop are not the load the assumption was made about, and
     // the timestamp path stayed alive in the multi-cycle kernels -- registers around the whole loop, and a wavefront per SIMD
     // in the OrientationState fp64 kernel).
-    const int64_t* const a_ts = (MULTI || PLAINL) ? nullptr : a.ts;
-    const double* const a_dt = (MULTI || PLAINL) ? nullptr : a.dt;
-    const uint8_t* const a_active = (MULTI || PLAINL) ? nullptr : a.active;
+    const int64_t* const a_ts = (MULTI || STREAMS_ONLY) ? nullptr : a.ts;
+    const double* const a_dt = (MULTI || STREAMS_ONLY) ? nullptr : a.dt;
+    const uint8_t* const a_active = (MULTI || STREAMS_ONLY) ? nullptr : a.active;
     const int32_t* const a_meas = PLAINL ? nullptr : a.meas;
-    const T gate_chi2_c = PLAINL ? T(-1) : T(a.gate_chi2);
-    const bool status_accumulate_c = PLAINL ? false : (a.status_accumulate != 0);
+    const T gate_chi2_c = STREAMS_ONLY ? T(-1) : T(a.gate_chi2);
+    const bool status_accumulate_c = STREAMS_ONLY ? false : (a.status_accumulate != 0);
     if constexpr (MULTI) {
         // multi-cycle launches are direct launches with one dt per cycle for every filter (checked by the host): no
         // per-filter timestamps, time steps, activity flags or filter index list to keep alive
@@ -1023,6 +1050,10 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 #pragma unroll
             for (int s = 0; s < S; ++s)
                 if (s < NL + 1) ref[s] = row_bcast<D>(xp[s]);   // stored 0..NL: the nonlinear components incl. the quaternion
+            // (lanes >= D hold the propagated CENTRE as both of their points -- their column is zero, the process model ran on the same
+            // bits twice.  Against the centre itself, the reference of the FIRST iteration, their deltas are exactly zero in the
+            // Euclidean components and log(conj(q) q), zero to ~1e-17, in the rotation: that sum needs no per-lane weights.  The later
+            // iterations do -- their reference has moved, and the centre counts once, not 2 (16 - D) times.)
             const bool has_p = has_pair || has_ctr, has_m = has_pair;
             const T wp = has_p ? T(1) : T(0), wm = has_m ? T(1) : T(0);
 
@@ -1036,14 +1067,13 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     const T qp[4] = {xp[Q], xp[Q + 1], xp[Q + 2], xp[Q + 3]};
                     const T qm[4] = {xm[Q], xm[Q + 1], xm[Q + 2], xm[Q + 3]};
                     T rp[3], rm[3];
-                    rot_minus_n(qp, qr, qn2, rp);
-                    rot_minus_n(qm, qr, qn2, rm);
+                    rot_minus_n2(qp, qm, qr, qn2, rp, rm);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) loc[RT + k] = fma(wm, rm[k], wp * rp[k]);
+                    for (int k = 0; k < 3; ++k) loc[RT + k] = rp[k] + rm[k];
                 }
 #pragma unroll
                 for (int t = 0; t < NL; ++t)
-                    if (t < RT || t >= RT + 3) loc[t] = fma(wm, xm[st_of(t)] - ref[st_of(t)], wp * (xp[st_of(t)] - ref[st_of(t)]));
+                    if (t < RT || t >= RT + 3) loc[t] = (xm[st_of(t)] - ref[st_of(t)]) + (xp[st_of(t)] - ref[st_of(t)]);
                 T md[NL];
                 if constexpr (sizeof(T) == 8) {
                     // fp64 has no DPP butterfly (12 VALU per value); transpose through the (free) factor region:
@@ -1139,8 +1169,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     ++wave_trips;
 #endif
                     T rp[3], rm[3], mr[3];
-                    rot_minus_n(qp, qr, qn2, rp);
-                    rot_minus_n(qm, qr, qn2, rm);
+                    rot_minus_n2(qp, qm, qr, qn2, rp, rm);
                     T m2 = T(0);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) mr[k] = fma(wm, rm[k], wp * rp[k]);
@@ -1199,8 +1228,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     so3_rebase_small(rpl, al, a2, rp);
                     so3_rebase_small(rml, al, a2, rm);
                 } else {
-                    rot_minus_n(qp, qr, qn2, rp);
-                    rot_minus_n(qm, qr, qn2, rm);
+                    rot_minus_n2(qp, qm, qr, qn2, rp, rm);
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -1449,7 +1477,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     // flight, the shaped-noise table is neither filled nor read -- a second copy of the loop under a wave-uniform
                     // branch, because a branch per entry makes the register allocator spill)
                     auto store_tiles = [&](auto plain_c) {
-                        constexpr bool PLAIN = decltype(plain_c)::value;
+                        constexpr bool PLAIN_NOISE = decltype(plain_c)::value;
 #pragma unroll
                         for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
@@ -1459,7 +1487,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                                 const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
                                 T nv = nz[i2][j2];
                                 if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
-                                    if constexpr (PLAIN) {
+                                    if constexpr (PLAIN_NOISE) {
                                         nv = pl[i2][j2];
                                     } else {
                                         const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
@@ -1619,9 +1647,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     const T cr[3] = {colp[RT] * w, colp[RT + 1] * w, colp[RT + 2] * w};
                     T e[4], qp[4], qm[4];
                     so3_exp_fast(cr, T(1), e);
-                    const T ec[4] = {-e[0], -e[1], -e[2], e[3]};
-                    quat_mul(q0, e, qp);
-                    quat_mul(q0, ec, qm);
+                    quat_mul_pm(q0, e, qp, qm);
                     MT<M>::gen_measure(qp, qm, q0, MUS, colp, w, zp, zm, z0);
                 }
                 sfence();
@@ -1771,7 +1797,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             sfence();
             UKFB_MARK("u_downdate_chol");
             // ---- Sigma' = Sigma - (K S) K^T, row l on lane l; delta on every lane
-            T srow2[D], d0[D];
+            T srow2[D], drot[3];
             bool ok2;
             T rs2;
             {
@@ -1787,7 +1813,7 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     fmac_bcast<b>(arow2[b], Kr[1], nks[1]);
                     fmac_bcast<b>(arow2[b], Kr[2], nks[2]);
                     srow2[b] = arow2[b];
-                    d0[b] = row_bcast<b>(del);
+                    if constexpr (b >= RT && b < RT + 3) drot[b - RT] = row_bcast<b>(del);   // the rotation part of delta, on every lane
                 });
                 UKFB_PRIO(1);
                 rs2 = chol16<T, D, LS, D, RT + 3>(arow2, Lc, l, ok2);   // applyDelta reads the first RT + 3 columns only
@@ -1810,11 +1836,15 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 T c3[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) c3[k] = Lc[cidx * LS + RT + k] * wc;
-                const T v0[3] = {d0[RT], d0[RT + 1], d0[RT + 2]};
+                const T v0[3] = {drot[0], drot[1], drot[2]};
                 const T vs[3] = {v0[0] + c3[0], v0[1] + c3[1], v0[2] + c3[2]};
                 T es[4];
-                so3_exp_fast(v0, T(1), e0);
                 so3_exp_fast(vs, T(1), es);
+                // exp(delta_r) itself: lanes 2 NC .. 15 hold no signed column (wc = 0), their `es` IS exp(v0 + 0) -- one broadcast per
+                // component instead of a second exponential on every lane
+                static_assert(2 * NC < 16, "a lane without a signed column exists");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e0[k] = row_bcast<15>(es[k]);
                 rot_minus_n(es, e0, T(1), rsg);   // log(conj(q e0) (q e+-)) = log(conj(e0) e+-): unit quaternions
             }
             sfence();
@@ -1889,24 +1919,22 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             }
             sfence();
             UKFB_MARK("u_mean");
-            // ---- new mean mu [+] delta (lane 0 writes the staging copy)
+            // ---- new mean mu [+] delta: lane l < D adds ITS component of delta (it holds row l of the gain, so `del` is delta[l]) to the
+            // stored component it belongs to; the three rotation lanes and lane 0 store the quaternion mu.q * exp(delta_r) instead
             {
-                T mu_r[S], nm[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) mu_r[s] = MUS[s];
-                const T q[4] = {mu_r[Q], mu_r[Q + 1], mu_r[Q + 2], mu_r[Q + 3]};
+                const T q[4] = {MUS[Q], MUS[Q + 1], MUS[Q + 2], MUS[Q + 3]};
                 T nq[4];
                 quat_mul(q, e0, nq);
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (s < Q) nm[s] = mu_r[s] + d0[s];
-                    else if (s >= Q + 4) nm[s] = mu_r[s] + d0[s - 1];
-                    else nm[s] = nq[s - Q];
-                }
+                const bool rotl = (l >= RT) && (l < RT + 3);
+                const int sl = (l < RT) ? l : (l + 1);                     // stored index of tangent component l outside the rotation
+                const bool eu = u_commit && has_pair && !rotl;
+                T old = MUS[has_pair ? sl : 0];
+                keep(old);
                 wsync();  // all lanes have read the old mean
-                T* dst = (u_commit && l == 0) ? MUS : DUMP;
+                MUS[eu ? sl : (LY::DUM - LY::MUS)] = old + del;
+                T* dst = (u_commit && l == 0) ? (MUS + Q) : DUMP;
 #pragma unroll
-                for (int s = 0; s < S; ++s) dst[s] = nm[s];
+                for (int k = 0; k < 4; ++k) dst[k] = nq[k];
             }
             wsync();
         }

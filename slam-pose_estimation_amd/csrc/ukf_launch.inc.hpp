@@ -37,12 +37,36 @@ template <class T, class M, int G> static int launch_g(ukfb_engine* e, const Lau
     return UKFB_OK;
 }
 
+// The instantiation of the tuned kernel for a launch shape: go(kernel) is called with the matching ukf_kernel16<...> (one of
+// twelve per (engine precision, model, compute type)).  level: 0 general, 1 streams only, 2 plain (ukf_kernel16.hpp).
+template <class T, class M, class TC, class Go>
+static void with_kernel16(bool indirect, bool multi, bool do_predict, bool do_update, int level, Go&& go) {
+    using MC = typename M::template rebind<TC>;
+    if (indirect) {
+        if (level >= 1) go(ukf_kernel16<TC, MC, true, true, false, true, 1, T>);
+        else go(ukf_kernel16<TC, MC, true, true, false, true, 0, T>);
+    } else if (multi) {
+        if (level == 2) go(ukf_kernel16<TC, MC, true, true, true, false, 2, T>);
+        else go(ukf_kernel16<TC, MC, true, true, true, false, 0, T>);
+    } else if (do_predict && do_update) {
+        if (level == 2) go(ukf_kernel16<TC, MC, true, true, false, false, 2, T>);
+        else if (level == 1) go(ukf_kernel16<TC, MC, true, true, false, false, 1, T>);
+        else go(ukf_kernel16<TC, MC, true, true, false, false, 0, T>);
+    } else if (do_predict) {
+        if (level >= 1) go(ukf_kernel16<TC, MC, true, false, false, false, 2, T>);
+        else go(ukf_kernel16<TC, MC, true, false, false, false, 0, T>);
+    } else {
+        if (level == 2) go(ukf_kernel16<TC, MC, false, true, false, false, 2, T>);
+        else if (level == 1) go(ukf_kernel16<TC, MC, false, true, false, false, 1, T>);
+        else go(ukf_kernel16<TC, MC, false, true, false, false, 0, T>);
+    }
+}
+
 #if defined(UKFB_STAMPS) || defined(UKFB_COUNTS)
 // Diagnostic builds (tools/phase_stamps.py, tools/trip_counts.py): every launch is synchronous; the per-marker s_memtime stamps of
 // all wavefronts are reduced to mean cycles between consecutive executed markers and appended to the file
 // named by UKFB_STAMP_OUT (one line per launch: kernel name, then marker_index:mean_delta pairs).
-template <class T, class M, class TC = T> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds, bool plain) {
-    using MC = typename M::template rebind<TC>;   // (stamped builds: the kernel's own manifold type)
+template <class T, class M, class TC = T> static int launch_row16_stamped(ukfb_engine* e, const LaunchReq& r, KArgs<T> args, int64_t grid, int lds, int level) {
     static unsigned long long* dbuf = nullptr;
     static size_t dcap = 0;
     const size_t need = size_t(grid) * UKFB_MAX_STAMPS;
@@ -60,20 +84,8 @@ template <class T, class M, class TC = T> static int launch_row16_stamped(ukfb_e
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(ukfb_dbg), zero, sizeof(zero), 0, hipMemcpyHostToDevice, main_stream(e));
     }
 #endif
-    if (args.fidx)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, true, false, T>), gd, bd, lds, main_stream(e), args);
-    else if (r.cycles > 0 && plain)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, true, T>), gd, bd, lds, main_stream(e), args);
-    else if (r.cycles > 0)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, false, T>), gd, bd, lds, main_stream(e), args);
-    else if (plain)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, true, T>), gd, bd, lds, main_stream(e), args);
-    else if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
-    else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, false, false, false, false, T>), gd, bd, lds, main_stream(e), args);
-    else
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, false, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
+    with_kernel16<T, M, TC>(args.fidx != nullptr, r.cycles > 0, r.do_predict, r.do_update, level,
+                            [&](auto kern) { hipLaunchKernelGGL(kern, gd, bd, lds, main_stream(e), args); });
     if (hipStreamSynchronize(main_stream(e)) != hipSuccess) return UKFB_ERR_HIP;
     const char* path = getenv("UKFB_STAMP_OUT");
     if (!path) return UKFB_OK;
@@ -155,14 +167,26 @@ template <class T, class M, class TC = T> static int launch_row16(ukfb_engine* e
     static const int lds_pad = [] { const char* s = std::getenv("UKFB_LDS_PAD_BYTES"); return s ? std::atoi(s) : 0; }();
     const int lds = FPW * lds_bytes_per_filter16<TC, MC>() + lds_pad;
     const bool multi = r.cycles > 0;   // ukfb_cycle_multi_dev: fused cycles only (checked by the caller)
-    // the plain instantiation (ukf_kernel16<..., PLAINL>): everything the kernel may then take as a compile-time fact
+    // What the kernel may take as compile-time facts about this launch (ukf_kernel16<..., PLAIN>):
+    //   streams only (level 1)  no per-filter timestamps / time steps / activity flags, the accept-any gate, a fresh status word
+    //   plain        (level 2)  ... and ONE full-3-vector measurement model for the launch (prediction-only launches: level 1 = 2)
+    // Indirect launches qualify for level 1 when their list is a bucketed filter list (event rounds carry timestamps); multi-cycle
+    // launches for level 2 when they have no schedule.
     const char* const plain_env = std::getenv("UKFB_NO_PLAIN_KERNEL");   // (A/B and tests: =1 keeps the general kernel; read per launch)
     const bool plain_off = plain_env && plain_env[0] == '1';
-    const bool plain = !plain_off && (!multi || !args.cyc_sched) && r.do_predict && r.do_update && !args.fidx && !args.ts && !args.dt && !args.meas && !args.active &&
-                       !args.status_accumulate && args.gate_chi2 < T(0) &&
-                       (M::MODEL != 0 ? args.meas_uniform == 9
-                                      : (args.meas_uniform == 0 || args.meas_uniform == 4 || args.meas_uniform == 8));
-    const char* mode = multi ? (plain ? "multicycle-plain" : "multicycle") : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : (plain ? "cycle-plain" : "cycle")) : "predict") : "update");
+    const bool streams_only = !plain_off && !args.ts && !args.dt && !args.active && !args.status_accumulate && args.gate_chi2 < T(0) &&
+                              (!multi || !args.cyc_sched) && (!args.fidx || args.fidx_inputs);
+    const bool full3 = !args.meas && (M::MODEL != 0 ? args.meas_uniform == 9
+                                                    : (args.meas_uniform == 0 || args.meas_uniform == 4 || args.meas_uniform == 8));
+    int level = 0;
+    if (streams_only) {
+        if (args.fidx) level = 1;
+        else if (multi) level = full3 ? 2 : 0;
+        else if (!r.do_update) level = 2;
+        else level = full3 ? 2 : 1;
+    }
+    const char* const suffix = level == 2 ? "-plain" : (level == 1 ? "-streams" : "");
+    const std::string mode = std::string(multi ? "multicycle" : (r.do_predict ? (r.do_update ? (args.fidx_inputs ? "cycle-bucketed" : "cycle") : "predict") : "update")) + suffix;
     e->last_kernel = std::string("ukf_kernel16<") + (sizeof(T) == 8 ? "f64" : (sizeof(TC) == 8 ? "f32-wide" : "f32")) + "," +
                      (M::MODEL == 0 ? "pose" : "orient") + "," + mode + ">";
     e->last_lds = lds;
@@ -171,7 +195,7 @@ template <class T, class M, class TC = T> static int launch_row16(ukfb_engine* e
     if (grid == 0) return UKFB_OK;
     const dim3 gd((unsigned)grid), bd(64);
 #if defined(UKFB_STAMPS) || defined(UKFB_COUNTS)
-    return launch_row16_stamped<T, M, TC>(e, r, args, grid, lds, plain);
+    return launch_row16_stamped<T, M, TC>(e, r, args, grid, lds, level);
 #endif
     // Two half launches on two streams (engines that own their stream, direct launches of SPLIT_MIN <= n < SPLIT_MAX filters):
     // launch k + 1's first half follows launch k's first half on `stream`, its second half follows launch k's second half on
@@ -189,12 +213,7 @@ template <class T, class M, class TC = T> static int launch_row16(ukfb_engine* e
             hipLaunchKernelGGL(kern, g1, bd, lds, sa, h1);
             hipLaunchKernelGGL(kern, g2, bd, lds, sb, h2);
         };
-        if (multi && plain) go(ukf_kernel16<TC, MC, true, true, true, false, true, T>);
-        else if (multi) go(ukf_kernel16<TC, MC, true, true, true, false, false, T>);
-        else if (plain) go(ukf_kernel16<TC, MC, true, true, false, false, true, T>);
-        else if (r.do_predict && r.do_update) go(ukf_kernel16<TC, MC, true, true, false, false, false, T>);
-        else if (r.do_predict) go(ukf_kernel16<TC, MC, true, false, false, false, false, T>);
-        else go(ukf_kernel16<TC, MC, false, true, false, false, false, T>);
+        with_kernel16<T, M, TC>(false, multi, r.do_predict, r.do_update, level, go);
         e->split_pending = true;
         const hipError_t serr = hipGetLastError();
         if (serr != hipSuccess) {
@@ -208,19 +227,9 @@ template <class T, class M, class TC = T> static int launch_row16(ukfb_engine* e
             set_error("indirect launches run the single fused cycle", hipErrorInvalidValue);
             return UKFB_ERR_INVALID_ARG;
         }
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, true, false, T>), gd, bd, lds, main_stream(e), args);
-    } else if (multi && plain)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, true, T>), gd, bd, lds, main_stream(e), args);
-    else if (multi)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, true, false, false, T>), gd, bd, lds, main_stream(e), args);
-    else if (plain)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, true, T>), gd, bd, lds, main_stream(e), args);
-    else if (r.do_predict && r.do_update)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
-    else if (r.do_predict)
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, true, false, false, false, false, T>), gd, bd, lds, main_stream(e), args);
-    else
-        hipLaunchKernelGGL((ukf_kernel16<TC, MC, false, true, false, false, false, T>), gd, bd, lds, main_stream(e), args);
+    }
+    with_kernel16<T, M, TC>(args.fidx != nullptr, multi, r.do_predict, r.do_update, level,
+                            [&](auto kern) { hipLaunchKernelGGL(kern, gd, bd, lds, main_stream(e), args); });
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         set_error("kernel launch", err);

@@ -136,20 +136,29 @@ class BatchUKF:
 
     def __init__(self, model: int, precision: int, capacity: int, device: int = 0, stream=None,
                  lanes_per_filter: int = 0, **cfg):
-        """stream: None = torch's CURRENT stream on `device` when torch is imported and sees a GPU (tensors
-        the caller produces with torch and hands to the "_dev" entry points are then ordered with the engine's launches
-        without any synchronise), otherwise an engine-owned stream; "private" = always an engine-owned non-blocking
-        stream (bench.py: nothing else shares the timed stream); an int = that hipStream_t."""
+        """stream:
+          "private"  an engine-owned non-blocking stream, what ukfb_create gives a C caller (bench.py: nothing else shares
+                     the timed stream; small batches run as split launches on two internal streams, ukfb_config.split_streams);
+          "torch"    torch's CURRENT stream on `device` (tensors the caller produces with torch and hands to the "_dev" entry
+                     points are then ordered with the engine's launches without any synchronise); raises without torch / a GPU;
+          an int     that hipStream_t;
+          None       "torch" when torch is imported and sees a GPU, else "private" -- the convenient default of this binding;
+                     `stream_kind` ("private" / "torch" / "given") tells which one an engine got."""
         self._lib = load_library()
         self._h = C.c_void_p()
         args = (C.byref(self._h), C.c_int(model), C.c_int(precision), C.c_int64(capacity), C.c_int(device))
-        if stream is None:
-            stream = _torch_current_stream(device)
-        if stream == "private" or stream is None:
+        kind = "given"
+        if stream is None or stream == "torch":
+            ts = _torch_current_stream(device)
+            if ts is None and stream == "torch":
+                raise UkfbError('stream="torch" needs torch with a visible GPU')
+            kind = "torch" if ts is not None else "private"
+            stream = ts if ts is not None else "private"
+        if stream == "private":
             self.stream_kind = "private"
             _chk(self._lib.ukfb_create(*args, None), "ukfb_create")
         else:
-            self.stream_kind = "given"
+            self.stream_kind = kind
             _chk(self._lib.ukfb_create_on_stream(*args, C.c_void_p(int(stream)) if int(stream) else None), "ukfb_create_on_stream")
         self.model, self.precision, self.capacity, self.device = model, precision, int(capacity), device
         self.S = 13 if model == MODEL_POSE else 14

@@ -13,6 +13,7 @@
 #include <pose_estimation/Measurement.hpp>
 #include <pose_estimation/orientation_estimator/OrientationState.hpp>
 #include <pose_estimation/orientation_estimator/OrientationUKF.hpp>
+#include <pose_estimation/orientation_estimator/OrientationUKFNoise.hpp>
 #include <pose_estimation/pose_with_velocity/BodyStateMeasurement.hpp>
 #include <pose_estimation/pose_with_velocity/PoseUKF.hpp>
 #include <pose_estimation/pose_with_velocity/PoseWithVelocity.hpp>
@@ -197,6 +198,35 @@ int main(int argc, char** argv)
     MTK::setDiagonal(oc, &OrientationState::bias_gyro, 1e-6);
     MTK::setDiagonal(oc, &OrientationState::gravity, 1e-8);
     CHECK(oc(6, 6) == 1e-6 && oc(8, 8) == 1e-6 && oc(9, 9) == 0.0 && oc(12, 12) == 1e-8 && oc(5, 5) == 0.0);
+
+    // OrientationUKFConfig -> initial state, initial covariance, process noise (OrientationUKFNoise.hpp; the formulas are this
+    // package's, the reference holds none: checked here against their closed forms)
+    OrientationUKFConfig cfg;
+    cfg.rotation_rate.randomwalk = Eigen::Vector3d(1e-3, 2e-3, 3e-3);
+    cfg.rotation_rate.bias_offset = Eigen::Vector3d(1e-4, -2e-4, 0.0);
+    cfg.rotation_rate.bias_instability = Eigen::Vector3d(1e-5, 1e-5, 2e-5);
+    cfg.rotation_rate.bias_tau = 3600.0;
+    cfg.acceleration.randomwalk = Eigen::Vector3d(1e-2, 1e-2, 2e-2);
+    cfg.acceleration.bias_offset = Eigen::Vector3d(0.0, 0.01, -0.02);
+    cfg.acceleration.bias_instability = Eigen::Vector3d(1e-3, 1e-3, 1e-3);
+    cfg.acceleration.bias_tau = 1800.0;
+    cfg.location.latitude = 0.92698121;     // the latitude of the reference's own test (test/test_coordinate_projection.cpp:11)
+    cfg.location.longitude = 0.15;
+    cfg.location.altitude = 12.0;
+    cfg.max_velocity = Eigen::Vector3d(3.0, 3.0, 1.5);
+    const OrientationUKFNoise::Covariance pn = OrientationUKFNoise::processNoise(cfg, 0.01);
+    CHECK(std::fabs(pn(1, 1) - 4e-6 / 0.01) < 1e-18 && std::fabs(pn(5, 5) - 4e-4 / 0.01) < 1e-16 && pn(0, 1) == 0.0 && pn(12, 12) == 0.0);
+    CHECK(std::fabs(pn(8, 8) - 2.0 * 4e-10 / (3600.0 * 0.01)) < 1e-24 && std::fabs(pn(9, 9) - 2.0 * 1e-6 / (1800.0 * 0.01)) < 1e-20);
+    // one step of dt = T: the reference scales by delta^2 -> orientation variance rw^2 T, bias variance 2 sigma^2 T / tau
+    CHECK(std::fabs(0.01 * 0.01 * pn(0, 0) - 1e-6 * 0.01) < 1e-20);
+    const OrientationState x_init = OrientationUKFNoise::initialState(cfg);
+    CHECK(x_init.orientation.w() == 1.0 && x_init.velocity[0] == 0.0 && x_init.bias_gyro[1] == -2e-4 && x_init.bias_acc[2] == -0.02);
+    CHECK(std::fabs(x_init.gravity(0) - GravitationalModel::WGS_84(0.92698121, 12.0)) == 0.0 && x_init.gravity(0) > 9.78 && x_init.gravity(0) < 9.84);
+    const OrientationUKFNoise::Covariance p_init = OrientationUKFNoise::initialCovariance(cfg, 0.05);
+    CHECK(std::fabs(p_init(2, 2) - 0.0025) < 1e-18 && p_init(3, 3) == 1.0 && p_init(5, 5) == 0.25 && std::fabs(p_init(8, 8) - 4e-10) < 1e-24 && std::fabs(p_init(12, 12) - 1e-4) < 1e-18);
+    bool threw = false;
+    try { OrientationUKFNoise::processNoise(cfg, 0.0); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
 
     // measurement structs and the Eigen spellings of the reference's headers
     SonarRange m;

@@ -85,6 +85,48 @@ def test_pose_fused_cycle_equals_predict_then_update(spe, oracle, prec, G):
     assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
 
 
+@pytest.mark.parametrize("stream", ["torch", "private"])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_core_parity_on_both_stream_kinds(spe, oracle, prec, stream):
+    """The binding's default (stream=None) puts an engine on torch's current stream; a C caller's ukfb_create gives it a private
+    stream, where batches of 16 384 ... 262 143 filters run as split launches on two internal streams (ukfb_config.split_streams).
+    The same parity holds on both: separate predict / update launches and the fused cycle, Pose and OrientationState, on a batch
+    that splits."""
+    n = 16_390
+    s = spe.synth
+    mu, cov = s.pose_initial(n)
+    acc, z, Q = s.pose_cycle_inputs(n, 0, mu[:, :3])
+    acc_cov = 0.01 * np.eye(3)
+    R = s.pose_default_process_noise()
+    eng = spe.BatchPoseUKF(n, precision=prec, stream=stream)
+    assert eng.stream_kind == stream and eng.config().split_streams == 1
+    eng.initialize(mu, cov)
+    eng.set_acceleration(acc, acc_cov)
+    eng.predict(0.01)
+    eng.update(spe.MEAS_POS3, z, Q)
+    eng.cycle(0.01, spe.MEAS_VEL3, mu[:, 7:10] + 0.01, Q)
+    m_g, c_g, _ = eng.state()
+    m_o, c_o, _ = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
+    m_o, c_o, _ = oracle.pose_update(m_o, c_o, spe.MEAS_POS3, z, Q)
+    m_o, c_o, _ = oracle.pose_predict(m_o, c_o, R, acc, acc_cov, 0.01)
+    m_o, c_o, _ = oracle.pose_update(m_o, c_o, spe.MEAS_VEL3, mu[:, 7:10] + 0.01, Q)
+    assert eng.status_summary() == 0
+    assert max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    eng.close()
+    mu, cov = s.orient_initial(n)
+    gyro, acc, z, Q = s.orient_cycle_inputs(n, 0, mu[:, :4])
+    eng = spe.BatchOrientationUKF(n, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE, precision=prec, stream=stream)
+    eng.initialize(mu, cov)
+    eng.set_process_noise(s.orient_process_noise())
+    eng.set_orient_inputs(gyro, acc)
+    eng.cycle(0.01, spe.MEAS_ORIENT_BODYVEL3, z, Q)
+    m_g, c_g, _ = eng.state()
+    m_o, c_o, _ = oracle.orient_predict(mu, cov, s.orient_process_noise(), acc, gyro, s.ORIENT_TAU, s.ORIENT_TAU, eng.earth_rotation, 0.01)
+    m_o, c_o, _ = oracle.orient_update(m_o, c_o, z, Q)
+    assert eng.status_summary() == 0 and max_abs(m_g, m_o) <= TOL[prec] and max_abs(c_g, c_o) <= TOL[prec]
+    eng.close()
+
+
 def test_pose_mixed_models_and_inactive_filters(spe, oracle):
     """BASELINE config 5 shape: per-filter model ids, 25 % inactive."""
     n = 1021

@@ -274,7 +274,7 @@ def test_full_size_config5_mixed_fp64(spe, oracle):
         eng.cycle_dev(0.01, spe.MEAS_POS3, xs[1], xs[2], meas_model_dev=xs[3])
         assert (eng.status_summary() & ~spe.ST_INACTIVE) == 0
         # (per-filter model ids on >= 16 384 filters: grouped by update class first, one indirect launch over the groups)
-        assert eng.last_launch_info()["kernel"] == "ukf_kernel16<f64,pose,cycle-bucketed>"
+        assert eng.last_launch_info()["kernel"] == "ukf_kernel16<f64,pose,cycle-bucketed-streams>"
     ponly.set_acceleration(None, acc_cov); ponly.bind_acceleration_dev(a_t); ponly.predict(0.01)
     m_f, c_f, _ = full.state(); st = full.status()
     off = models_all < 0

@@ -61,7 +61,8 @@ def test_pose_plain_launch_equals_the_general_kernel(spe, prec, n):
         return m, c, st, names
 
     (m1, c1, st1, names1), (m0, c0, st0, names0) = _twice(run)
-    assert all(k.endswith(",cycle-plain>") for k in names1[:4]) and names1[4].endswith(",cycle>") and names1[5].endswith(",multicycle-plain>")
+    # (POS_XY is not a full 3-vector: the streams-only level -- no per-filter streams, the general model tables)
+    assert all(k.endswith(",cycle-plain>") for k in names1[:4]) and names1[4].endswith(",cycle-streams>") and names1[5].endswith(",multicycle-plain>")
     assert all(k.endswith(",cycle>") for k in names0[:5]) and names0[5].endswith(",multicycle>")
     assert np.array_equal(m1, m0, equal_nan=True) and np.array_equal(c1, c0, equal_nan=True) and (st1 == st0).all()
     assert (st1[5] & spe.ST_ERR_CHOLESKY) and (st1[n - 1] & spe.ST_UNINITIALISED) and st1[6] == 0
@@ -102,6 +103,49 @@ def test_orientation_plain_launch_equals_the_general_kernel(spe, prec):
     assert np.array_equal(m1, m0) and np.array_equal(c1, c0) and (st1 == st0).all() and (st1 == 0).all()
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+def test_plain_levels_of_separate_predict_and_update_launches(spe, prec):
+    """Callers that keep the reference's two calls (predictionStep, then integrateMeasurement: UnscentedKalmanFilter.hpp:107-125,
+    PoseUKF.cpp:112-173) get plain instantiations as well: prediction-only, and update-only at level 2 (one full-3-vector model)
+    or level 1 (any uniform model / per-filter models) -- bit-identical with the general kernels, incl. an activity mask or a
+    gate, which keep the general kernel."""
+    import torch
+    s = spe.synth
+    n = 4099
+    tdt = torch.float64 if prec == 0 else torch.float32
+    mu, cov = s.pose_initial(n)
+    cov[5] = -cov[5]
+    acc, z, Q = s.pose_cycle_inputs(n, 0, mu[:, :3], random_q=True)
+    models = s.pose_mixed_models(n, 0)
+    zm = s.pose_measurement_for_model(mu, models, z - mu[:, :3])
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x.reshape(x.shape[0], -1))).to("cuda", tdt)   # noqa: E731
+    z_t, Q_t, zm_t = dev(z), dev(Q), dev(zm)
+    m_t = torch.from_numpy(models).to("cuda")
+    torch.cuda.synchronize()
+
+    def run():
+        e = spe.BatchPoseUKF(n, precision=prec, stream="private")
+        e.initialize(mu[:n - 2], cov[:n - 2])
+        e.set_acceleration(acc, 0.01 * np.eye(3))
+        names = []
+        e.predict(0.01); names.append(e.last_launch_info()["kernel"])
+        e.update_dev(spe.MEAS_POS3, z_t, Q_t); names.append(e.last_launch_info()["kernel"])
+        e.predict(0.02); e.update_dev(spe.MEAS_POS_XY, z_t, Q_t); names.append(e.last_launch_info()["kernel"])
+        e.predict(0.01); e.update_dev(0, zm_t, Q_t, meas_model_dev=m_t); names.append(e.last_launch_info()["kernel"])
+        act = np.ones(n, dtype=np.uint8); act[::3] = 0
+        e.update(spe.MEAS_VEL3, mu[:, 7:10], Q, active=act); names.append(e.last_launch_info()["kernel"])
+        m, c, _ = e.state()
+        st = e.status()
+        e.close()
+        return m, c, st, names
+
+    (m1, c1, st1, names1), (m0, c0, st0, names0) = _twice(run)
+    assert [k.split(",")[-1] for k in names1] == ["predict-plain>", "update-plain>", "update-streams>", "update-streams>", "update>"]
+    assert [k.split(",")[-1] for k in names0] == ["predict>", "update>", "update>", "update>", "update>"]
+    assert np.array_equal(m1, m0, equal_nan=True) and np.array_equal(c1, c0, equal_nan=True) and (st1 == st0).all()
+    assert (st1[5] & spe.ST_ERR_CHOLESKY) and (st1[n - 1] & spe.ST_UNINITIALISED)
+
+
 def test_launches_that_do_not_qualify_keep_the_general_kernel(spe):
     import torch
     s = spe.synth
@@ -116,8 +160,8 @@ def test_launches_that_do_not_qualify_keep_the_general_kernel(spe):
     e.initialize(mu, cov)
     e.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t)
     assert e.last_launch_info()["kernel"].endswith("cycle-plain>")
-    e.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t, meas_model_dev=models_t)          # per-filter model ids
-    assert e.last_launch_info()["kernel"].endswith(",cycle>")
+    e.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t, meas_model_dev=models_t)          # per-filter model ids: streams only
+    assert e.last_launch_info()["kernel"].endswith(",cycle-streams>")
     e.cycle(0.01, spe.MEAS_POS3, z, Q)                                            # host arrays, same launch shape: plain again
     assert e.last_launch_info()["kernel"].endswith("cycle-plain>")
     e.cycle_timestamps(np.full(n, 5_000_000, dtype=np.int64), np.zeros(n, dtype=np.int32), z, Q)   # per-filter sample times

@@ -75,9 +75,9 @@ def test_wide_pose_launch_shapes_against_the_fp64_oracle(spe, oracle):
     # separate predict and update launches (the reference's two calls), general fused cycle (per-filter models incl. SO(3))
     e.initialize(mu, cov)
     e.predict(0.01)
-    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f32-wide,pose,predict>"
+    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f32-wide,pose,predict-plain>"
     e.update_dev(spe.MEAS_POS3, z_t, Q_t)
-    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f32-wide,pose,update>"
+    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f32-wide,pose,update-plain>"
     m_g2, c_g2, _ = e.state()
     assert rel_err(m_g2, m_o) <= 2 * STORE_TOL and rel_err(c_g2, c_o) <= 2 * STORE_TOL   # (one more rounding of the state in between)
 
@@ -86,7 +86,7 @@ def test_wide_pose_launch_shapes_against_the_fp64_oracle(spe, oracle):
     e.configure(bucket_models=0)
     e.initialize(mu, cov)
     e.cycle_dev(0.01, 0, dev(zm), Q_t, meas_model_dev=torch.from_numpy(models).to("cuda"))
-    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f32-wide,pose,cycle>"
+    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f32-wide,pose,cycle-streams>"
     m_o3, c_o3, _ = oracle.pose_predict(mu, cov, R, acc, acc_cov, 0.01)
     m_o3, c_o3, st3 = oracle.pose_update(m_o3, c_o3, models, zm, Q)
     m_g3, c_g3, _ = e.state()
@@ -191,7 +191,7 @@ def test_wide_flag_is_refused_or_ignored_where_it_does_not_apply(spe):
     mu, cov = spe.synth.pose_initial(64)
     e.initialize(mu, cov)
     e.predict(0.01)
-    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f64,pose,predict>"
+    assert e.last_launch_info()["kernel"] == "ukf_kernel16<f64,pose,predict-plain>"
     e.close()
     e = spe.BatchPoseUKF(64, precision=spe.F32)
     with pytest.raises(spe.UkfbError):

@@ -12,6 +12,7 @@ out=$root/slam-pose_estimation_amd/lib/ab; obj=$out/obj_$name; mkdir -p $obj
 pids=""
 tus="ukf_batch ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32"
 [ -f $src/ukf_group.hip ] && tus="$tus ukf_group"     # (device groups: round 3 on)
+[ -f $src/ukf_launch_pose_f32w.hip ] && tus="$tus ukf_launch_pose_f32w ukf_launch_orient_f32w"   # (wide arithmetic: round 4 on)
 for tu in $tus; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize -DUKFB_GENERIC_F64=0 ${REV_FLAGS--mllvm -disable-machine-licm} -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.log &
   pids="$pids $!"

@@ -29,7 +29,7 @@ for tu in ukf_batch ukf_group; do
   /opt/rocm/bin/hipcc $common "$@" -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.remarks &
   pids="$pids $!"
 done
-for tu in ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32; do
+for tu in ukf_launch_pose_f64 ukf_launch_pose_f32 ukf_launch_orient_f64 ukf_launch_orient_f32 ukf_launch_pose_f32w ukf_launch_orient_f32w; do
   /opt/rocm/bin/hipcc $common -mllvm -disable-machine-licm "$@" \
       -Rpass-analysis=kernel-resource-usage -c $src/$tu.hip -o $obj/$tu.o 2> $obj/$tu.remarks &
   pids="$pids $!"

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Near-minimax polynomial fits for the engine's SO(3) maps (slam-pose_estimation_amd/csrc/ukf_device.hpp, struct Poly):
+cos(sqrt(y)), sin(sqrt(y))/sqrt(y) on [0, Y] and atan(sqrt(u))/sqrt(u) on [0, U].  Chebyshev interpolation at the Chebyshev
+nodes of the interval (50-digit arithmetic, mpmath), converted to monomial coefficients; the reported error is the maximum over
+4000 points of |p(x) - f(x)| with the coefficients ROUNDED to the target type and Horner evaluated in 50 digits, i.e. the
+approximation error alone (evaluation rounding comes on top).
+
+    python3 tools/fit_so3_polys.py cos 0.62 6       # function, interval end, degree
+    python3 tools/fit_so3_polys.py table             # the error table behind the choice of degrees
+"""
+import sys
+
+import mpmath as mp
+
+mp.mp.dps = 50
+
+
+def f_cos(y):
+    return mp.cos(mp.sqrt(y)) if y > 0 else mp.mpf(1)
+
+
+def f_sinc(y):
+    s = mp.sqrt(y)
+    return mp.sin(s) / s if y > 0 else mp.mpf(1)
+
+
+def f_atan(u):
+    s = mp.sqrt(u)
+    return mp.atan(s) / s if u > 0 else mp.mpf(1)
+
+
+FUN = {"cos": f_cos, "sinc": f_sinc, "atan": f_atan}
+
+
+def fit(fn, hi, deg, single=False):
+    f = FUN[fn]
+    n = deg + 1
+    xs = [mp.mpf(hi) / 2 * (1 + mp.cos(mp.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
+    A = mp.matrix(n, n)
+    b = mp.matrix(n, 1)
+    for i, x in enumerate(xs):
+        for j in range(n):
+            A[i, j] = x ** j
+        b[i] = f(x)
+    c = mp.lu_solve(A, b)
+    rnd = (lambda v: mp.mpf(float.fromhex(float(v).hex()))) if not single else (lambda v: mp.mpf(__import__("numpy").float32(float(v)).item()))
+    cr = [rnd(c[j]) for j in range(n)]
+    err = mp.mpf(0)
+    for k in range(4001):
+        x = mp.mpf(hi) * k / 4000
+        p = mp.mpf(0)
+        for j in reversed(range(n)):
+            p = p * x + cr[j]
+        err = max(err, abs(p - f(x)))
+    return cr, err
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "table":
+        for fn, his, degs in (("cos", (0.62, 0.36, 0.25), (4, 5, 6)), ("sinc", (0.62, 0.36, 0.25), (4, 5, 6)), ("atan", (0.07, 0.04), (5, 6, 7, 8))):
+            for hi in his:
+                print(f"{fn:5s} [0, {hi}]: " + "  ".join(f"deg {d}: {mp.nstr(fit(fn, hi, d)[1], 3)}" for d in degs))
+    else:
+        fn, hi, deg = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
+        single = len(sys.argv) > 4 and sys.argv[4] == "f32"
+        c, err = fit(fn, hi, deg, single)
+        print(f"{fn} on [0, {hi}], degree {deg}: max error {mp.nstr(err, 3)}")
+        print("{" + ", ".join(mp.nstr(v, 9 if single else 18) for v in c) + "}")

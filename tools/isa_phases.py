@@ -8,7 +8,8 @@ after `s_endpgm`-less cold jumps are attributed to the phase whose marker preced
 are counted once (the covariance loop prints its trip count in the source).  Use for RELATIVE accounting;
 the dynamic totals come from tools/phase_pmc.sh (SQ_INSTS_VALU).
 
-usage: tools/isa_phases.py [pose|orient] [f64|f32] [cycle|predict|update|multi|indirect|plain|multi-plain] [extra hipcc flags...]"""
+usage: tools/isa_phases.py [pose|orient] [f64|f32] [cycle|predict|update|multi|indirect|plain|multi-plain|streams|bucketed-streams|
+                            predict-plain|update-plain|update-streams] [extra hipcc flags...]"""
 import collections
 import os
 import re
@@ -55,8 +56,10 @@ def main():
                                "-mllvm", "-disable-machine-licm", "-DUKFB_PHASE_MARKS", "-S", "--cuda-device-only", "-o", out, tu] + extra,
                               stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
-    flags = {"cycle": "Lb1ELb1ELb0ELb0ELb0E", "predict": "Lb1ELb0ELb0ELb0ELb0E", "update": "Lb0ELb1ELb0ELb0ELb0E", "multi": "Lb1ELb1ELb1ELb0ELb0E",
-             "indirect": "Lb1ELb1ELb0ELb1ELb0E", "plain": "Lb1ELb1ELb0ELb0ELb1E", "multi-plain": "Lb1ELb1ELb1ELb0ELb1E"}[mode]
+    flags = {"cycle": "Lb1ELb1ELb0ELb0ELi0E", "predict": "Lb1ELb0ELb0ELb0ELi0E", "update": "Lb0ELb1ELb0ELb0ELi0E", "multi": "Lb1ELb1ELb1ELb0ELi0E",
+             "indirect": "Lb1ELb1ELb0ELb1ELi0E", "plain": "Lb1ELb1ELb0ELb0ELi2E", "multi-plain": "Lb1ELb1ELb1ELb0ELi2E",
+             "streams": "Lb1ELb1ELb0ELb0ELi1E", "bucketed-streams": "Lb1ELb1ELb0ELb1ELi1E", "predict-plain": "Lb1ELb0ELb0ELb0ELi2E",
+             "update-plain": "Lb0ELb1ELb0ELb0ELi2E", "update-streams": "Lb0ELb1ELb0ELb0ELi1E"}[mode]
     start = None
     for i, line in enumerate(text):
         if line.startswith("_ZN4ukfb12ukf_kernel16") and flags in line and line.rstrip().endswith(":") is False and ":" in line:

@@ -361,6 +361,28 @@ template <class T, class M, class TS = T> struct CovTab {
     static constexpr Tabs tabs = make();
 };
 
+// Lane constants of the update's assembly (every kernel): LDS byte offset of the lane's covariance row and of its three cross
+// entries with the rotation columns (symmetric position (max, min)) -- one 16-byte load per lane instead of ~20 integer
+// instructions of triangular indexing per wavefront.
+template <class T, class M> struct AsmTab {
+    using LY = Layout16<T, M>;
+    struct Tabs { uint32_t off[16][4]; };
+    static constexpr Tabs make() {
+        Tabs t{};
+        constexpr int RT = MT<M>::RT, SZ = int(sizeof(T));
+        for (int l = 0; l < 16; ++l) {
+            const int lr = l < M::D ? l : 0;
+            t.off[l][0] = uint32_t(LY::cv(lr, 0) * SZ);
+            for (int k = 0; k < 3; ++k) {
+                const int hi = lr > RT + k ? lr : RT + k, lo = lr > RT + k ? RT + k : lr;
+                t.off[l][1 + k] = uint32_t(LY::cv(hi, lo) * SZ);
+            }
+        }
+        return t;
+    }
+    static constexpr Tabs tabs = make();
+};
+
 // ---------------------------------------------------------------------------------------------
 // Cholesky: lane l < D holds row l (entries 0..l) in a[].  The factorisation itself runs on DPP row
 // broadcasts (lane c's A[c][k] for the trailing update, lane k's pivot); column k is published UNSCALED
@@ -482,7 +504,14 @@ template <class T> UKFB_DEV void rot_minus_n2(const T (&qxa)[4], const T (&qxb)[
     T da[4], db[4];
     quat_mul(oc, qxa, da);
     quat_mul(oc, qxb, db);
-    so3_log_fast_n2(da, db, nrm, ra, rb);
+    // fp32 (issue-bound, registers to spare at 6 wavefronts per SIMD): the paired form, +0.7 ... 1.2 % on configs 3 / 4.  fp64: the
+    // ten registers it holds more through the phase cost more than the interleaving gains (-0.6 % on the headline, same-box A/B).
+    if constexpr (sizeof(T) == 4) {
+        so3_log_fast_n2(da, db, nrm, ra, rb);
+    } else {
+        so3_log_fast_n(da, nrm, ra);
+        so3_log_fast_n(db, nrm, rb);
+    }
 }
 
 // the same with the norm of conj(y) * x known (see so3_log_fast_n)
@@ -1777,6 +1806,13 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
             }
             sfence();
             UKFB_MARK("u_gain");
+            // lane constants of the assembly phase, requested here so that they have arrived when it starts
+            uint32_t asmo[4];
+            {
+                const uint32_t* arow = AsmTab<T, M>::tabs.off[l];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) asmo[k] = arow[k];
+            }
             T Kr[3], KSr[3];
             bool accept;
             {
@@ -1898,17 +1934,16 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 // rowbase(l)) > c, i.e. earlier in this descending loop.  The last row has nothing beyond its diagonal.
                 // (The stores of one lane never alias each other, so the compiler would be free to reorder or pair
                 // them; the order that matters is between LANES, hence the compiler fence after every store.)
-                T* rowdst = wl ? (PKS + l * (l + 1) / 2) : DUMP;
+                unsigned char* const wbase = reinterpret_cast<unsigned char*>(base);
+                constexpr uint32_t SINK = uint32_t(LY::DUM * sizeof(T));
+                T* rowdst = reinterpret_cast<T*>(wbase + (wl ? asmo[0] : SINK));
 #pragma unroll
                 for (int b = D - 1; b >= 0; --b) {
                     rowdst[b] = srow2[b];
                     asm volatile("" ::: "memory");
                 }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int hi = l > RT + k ? l : RT + k, lo = l > RT + k ? RT + k : l;
-                    base[wl ? LY::cv(hi, lo) : LY::DUM] = cr[k];
-                }
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<T*>(wbase + (wl ? asmo[1 + k] : SINK)) = cr[k];
                 asm volatile("" ::: "memory");
                 const bool w0 = u_commit && l == 0;
 #pragma unroll

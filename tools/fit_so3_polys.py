@@ -5,7 +5,7 @@ nodes of the interval (50-digit arithmetic, mpmath), converted to monomial coeff
 4000 points of |p(x) - f(x)| with the coefficients ROUNDED to the target type and Horner evaluated in 50 digits, i.e. the
 approximation error alone (evaluation rounding comes on top).
 
-    python3 tools/fit_so3_polys.py cos 0.62 6       # function, interval end, degree
+    python3 tools/fit_so3_polys.py cos 0.62 6 [f32] [pin0]   # function, interval end, degree; pin0: constant term exactly 1
     python3 tools/fit_so3_polys.py table             # the error table behind the choice of degrees
 """
 import sys
@@ -32,7 +32,23 @@ def f_atan(u):
 FUN = {"cos": f_cos, "sinc": f_sinc, "atan": f_atan}
 
 
-def fit(fn, hi, deg, single=False):
+def fit(fn, hi, deg, single=False, pin0=False):
+    """pin0: the constant term is exactly f(0) = 1 (the fit is of g in f(x) = 1 + x g(x), degree deg - 1): exp(0) is then exactly
+    the identity quaternion and log of a unit-w quaternion exactly its vector part times 2"""
+    if pin0:
+        f0 = FUN[fn]
+        g = lambda x: (f0(x) - 1) / x if x > 0 else {"cos": mp.mpf(-1) / 2, "sinc": mp.mpf(-1) / 6, "atan": mp.mpf(-1) / 3}[fn]
+        FUN["_g"] = g
+        c, _ = fit("_g", hi, deg - 1, single)
+        cr = [mp.mpf(1)] + list(c)
+        err = mp.mpf(0)
+        for k in range(4001):
+            x = mp.mpf(hi) * k / 4000
+            p_ = mp.mpf(0)
+            for j in reversed(range(len(cr))):
+                p_ = p_ * x + cr[j]
+            err = max(err, abs(p_ - f0(x)))
+        return cr, err
     f = FUN[fn]
     n = deg + 1
     xs = [mp.mpf(hi) / 2 * (1 + mp.cos(mp.pi * (2 * k + 1) / (2 * n))) for k in range(n)]
@@ -62,7 +78,7 @@ if __name__ == "__main__":
                 print(f"{fn:5s} [0, {hi}]: " + "  ".join(f"deg {d}: {mp.nstr(fit(fn, hi, d)[1], 3)}" for d in degs))
     else:
         fn, hi, deg = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
-        single = len(sys.argv) > 4 and sys.argv[4] == "f32"
-        c, err = fit(fn, hi, deg, single)
+        single = "f32" in sys.argv[4:]
+        c, err = fit(fn, hi, deg, single, pin0="pin0" in sys.argv[4:])
         print(f"{fn} on [0, {hi}], degree {deg}: max error {mp.nstr(err, 3)}")
         print("{" + ", ".join(mp.nstr(v, 9 if single else 18) for v in c) + "}")

@@ -19,6 +19,10 @@
 #include "ukf_engine.hpp"
 
 namespace {
+// The covariance tiles of the OrientationState kernels are 3 x 3 on a 13 x 13 matrix: a lane whose tile hangs over the edge (rows 13,
+// 14) loads its noise entries with immediate offsets from the tile origin like every other lane and drops them -- up to 2 * 13 + 2
+// scalars past the last table.  Every noise allocation carries that many spare scalars (never written, never used).
+constexpr size_t NOISE_TABLE_PAD = 32;
 
 thread_local std::string g_last_error;
 thread_local bool g_wait_timed_out = false;   // the last bounded wait of this thread gave up (it wrote the error text itself)
@@ -345,7 +349,7 @@ int rebuild_racc(ukfb_engine* e) {
         }
         e->Racc = nullptr;
         e->Racc_mats = 0;
-        HIP_TRY(hipMalloc(&e->Racc, size_t(nmat) * dd * e->tsize));
+        HIP_TRY(hipMalloc(&e->Racc, (size_t(nmat) * dd + NOISE_TABLE_PAD) * e->tsize));
         e->Racc_mats = nmat;
     }
     if (!e->acc_cov_dev) HIP_TRY(hipMalloc(&e->acc_cov_dev, 9 * sizeof(double)));
@@ -731,7 +735,7 @@ static int create_engine(ukfb_engine* e, int64_t capacity, void* stream, bool us
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->status), n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->init), n));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->last_ts), n * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&e->Rn, size_t(e->D) * e->D * ts));
+    HIP_TRY(hipMalloc(&e->Rn, (size_t(e->D) * e->D + NOISE_TABLE_PAD) * ts));
     HIP_TRY(hipMalloc(&e->in_a, n * 3 * ts));
     HIP_TRY(hipMalloc(&e->in_b, n * 3 * ts));
     HIP_TRY(hipMalloc(&e->z_stage, n * 3 * ts));
@@ -1015,7 +1019,7 @@ int ukfb_set_process_noise_per_filter(ukfb_engine* e, int64_t first, int64_t cou
     const size_t dd = size_t(e->D) * e->D;
     if (!e->Rn_per_filter) {
         void* big = nullptr;
-        HIP_TRY(hipMalloc(&big, size_t(e->cap) * dd * e->tsize));
+        HIP_TRY(hipMalloc(&big, (size_t(e->cap) * dd + NOISE_TABLE_PAD) * e->tsize));
         ENGINE_SYNC(e);
         HIP_TRY(hipFree(e->Rn));
         e->Rn = big;

@@ -361,6 +361,73 @@ template <class T, class M, class TS = T> struct CovTab {
     static constexpr Tabs tabs = make();
 };
 
+// The same idea for the OrientationState kernels (round 4), whose 3 x 3 tiles on a 13 x 13 matrix made the decoded form expensive (tiles
+// that hang over the edge, rows of unequal length, scale classes of the affine block: ~215 integer / select instructions per
+// wavefront, most of them at the 4-cycle rate).  Round 2 tried 32-bit tables -- six 16-byte loads per lane -- and lost 1.4 %; here
+// every offset is 16 bits (LDS offsets inside one filter's slice, byte offsets inside one 13 x 13 noise table): 48 bytes per lane,
+// three loads.
+//   rd[l]   PR, PC (LDS bytes), FLAGS (bit 0: tile of the nonlinear block, i.e. the neighbour lane's half sum is added; bits 2..9:
+//           scale class 0 = gyro-bias, 1 = acc-bias, 2 = one of the row / column of the lane's two affine entries), NZ (byte offset
+//           of the tile origin in the noise table: the nine entries follow by immediate offsets, past the table's end for tiles
+//           that hang over -- the engine pads its noise allocations, ukf_batch.hip), ANZ0, ANZ1 (the affine entries' noise)
+//   wr[l]   nine tile store offsets (entries the lane does not own -- beyond the diagonal, outside the matrix, the second half
+//           lane of a shared tile, lanes >= WORK_LANES: the noise table's spare slot), two affine store offsets (sink for an
+//           entry past the triangle), two affine read offsets.  Row 16: every store to its sink (a filter that does not commit).
+template <class T, class M, class TS = T> struct OCovTab {
+    using LY = Layout16<T, M>;
+    static constexpr int D = M::D, NL = LY::NL, ST = LY::ST, TRIP = LY::TRIP, TR = MT<M>::TR, TC = MT<M>::TC;
+    static constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + 15) / 16, SZ = int(sizeof(T)), SZG = int(sizeof(TS));
+    static constexpr int RD_PR = 0, RD_PC = 1, RD_FLAGS = 2, RD_NZ = 3, RD_ANZ = 4, NRD = 8;
+    static constexpr int WR_TILE = 0, WR_AFF = TR * TC, WR_AFF_RD = TR * TC + AEL, NWR = 16;
+    static_assert(AEL == 2 && TR * TC + 2 * AEL <= NWR && RD_ANZ + AEL <= NRD, "OrientationState lane tables");
+    struct Tabs {
+        uint16_t rd[16][NRD];
+        uint16_t wr[17][NWR];
+    };
+    static constexpr int tri_r(int e) {
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        return r;
+    }
+    static constexpr int scale_class(int c) { return c < 9 ? 0 : (c < 12 ? 1 : 2); }   // MT<OrientM>::aff_scale
+    static constexpr Tabs make() {
+        Tabs t{};
+        const uint16_t tile_sink = uint16_t(LY::NSH_SINK * SZ), aff_sink = uint16_t(LY::DUM * SZ);
+        for (int l = 0; l < 16; ++l) {
+            const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
+            const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
+            const bool is_cross = R0 >= NL;
+            const int half = is_cross ? 0 : (lw & 1);
+            t.rd[l][RD_PR] = uint16_t((is_cross ? (LY::LAF + (R0 - NL)) : (LY::TNL + half * (TRIP * ST) + R0)) * SZ);
+            t.rd[l][RD_PC] = uint16_t((LY::TNL + ((is_cross || half) ? (TRIP * ST) : 0) + C0) * SZ);
+            t.rd[l][RD_NZ] = uint16_t((R0 * D + C0) * SZG);
+            unsigned flags = is_cross ? 0u : 1u;
+            const bool writer = (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
+            for (int i2 = 0; i2 < TR; ++i2)
+                for (int j2 = 0; j2 < TC; ++j2) {
+                    const int r = R0 + i2, c = C0 + j2;
+                    t.wr[l][WR_TILE + i2 * TC + j2] = (writer && r < D && c <= r) ? uint16_t(LY::cv(r, c) * SZ) : tile_sink;
+                }
+            for (int k = 0; k < AEL; ++k) {
+                const int e = l + 16 * k;
+                const bool v = e < NAB;
+                const int rr = v ? tri_r(e) : 0, cc = v ? (e - rr * (rr + 1) / 2) : 0;
+                const int ar = NL + rr, ac = NL + cc;
+                t.rd[l][RD_ANZ + k] = uint16_t((ar * D + ac) * SZG);
+                t.wr[l][WR_AFF + k] = v ? uint16_t(LY::cv(ar, ac) * SZ) : aff_sink;
+                t.wr[l][WR_AFF_RD + k] = uint16_t(LY::cv(ar, ac) * SZ);
+                flags |= unsigned(scale_class(ar)) << (2 + 4 * k);
+                flags |= unsigned(scale_class(ac)) << (4 + 4 * k);
+            }
+            t.rd[l][RD_FLAGS] = uint16_t(flags);
+        }
+        for (int k = 0; k < NWR; ++k) t.wr[16][k] = (k < WR_AFF) ? tile_sink : aff_sink;
+        for (int k = 0; k < AEL; ++k) t.wr[16][WR_AFF_RD + k] = uint16_t(LY::cv(NL, NL) * SZ);
+        return t;
+    }
+    static constexpr Tabs tabs = make();
+};
+
 // Lane constants of the update's assembly (every kernel): LDS byte offset of the lane's covariance row and of its three cross
 // entries with the rotation columns (symmetric position (max, min)) -- one 16-byte load per lane instead of ~20 integer
 // instructions of triangular indexing per wavefront.
@@ -1239,6 +1306,12 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
 #pragma unroll
                 for (int k = 0; k < CovTab<T, M, TS>::NRD; ++k) ctr[k] = rrow[k];
             }
+            uint32_t otr[4] = {0u, 0u, 0u, 0u};   // OrientationState: the lane's rd row, eight 16-bit values
+            if constexpr (M::MODEL != 0) {
+                const uint32_t* rrow = reinterpret_cast<const uint32_t*>(OCovTab<T, M, TS>::tabs.rd[l]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) otr[k] = rrow[k];
+            }
             {   // rotation deltas to the final mean; quaternion of the mean.  The loop's last trip took the logarithms
                 // against the reference BEFORE its (sub-tolerance) move al: re-base them to first order in al, exact in
                 // the delta (remainder < 4e-14 under the bounds tested here); anything else takes the logarithms again.
@@ -1387,82 +1460,45 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     *reinterpret_cast<T*>(wbase + ctw[CT::WR_AFF + t]) = old + anz[t];
                 }
             } else {
-                const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
-                const int R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull), C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
-                const bool is_cross = R0 >= NL;
-                const int half = is_cross ? 0 : (lw & 1);
-                const T* pr = is_cross ? (LAF + (R0 - NL)) : (TAB + half * (TRIP * ST) + R0);
-                const T* pc_ = TAB + ((is_cross || half) ? (TRIP * ST) : 0) + C0;   // cross: the W rows
-                // shaped process noise of this lane's tile: with a plain table (Pose acceleration branch) it is
-                // requested before the accumulation loop and consumed after it; the rotated form is evaluated late
-                // (it would hold 2 x TR x TC products in flight across the loop)
-                constexpr bool NZ_EARLY = (M::MODEL == 0);
-                constexpr bool TILES_INSIDE = (M::MODEL == 0);   // Pose: every tile entry is a valid (row, column); Orient: rows 13, 14 are not
-                static_assert(!TILES_INSIDE || (10 + TR <= D && 3 + TC <= NL), "Pose tile table");
-                constexpr int NAB = (D - NL) * (D - NL + 1) / 2, AEL = (NAB + G - 1) / G;   // affine block entries, per lane
+                // OrientationState: 3 x 3 tiles, lane constants from OCovTab (16-bit offsets, three loads per lane)
+                using OT = OCovTab<T, M, TS>;
+                static_assert(M::MODEL == 1, "the decoded form of this phase is gone: every model has lane tables");
+                constexpr int AEL = OT::AEL;
+                unsigned char* const wbase = reinterpret_cast<unsigned char*>(base);
+                const auto lo16 = [](uint32_t x) { return x & 0xFFFFu; };
+                const auto hi16 = [](uint32_t x) { return x >> 16; };
+                const T* pr = reinterpret_cast<const T*>(wbase + lo16(otr[0]));
+                const T* pc_ = reinterpret_cast<const T*>(wbase + hi16(otr[0]));   // cross: the W rows
+                const uint32_t flags = lo16(otr[1]);
+                // results: the row of the lane, or the all-sink row when this filter's prediction is not committed
+                uint32_t otw[OT::NWR / 2];
+                {
+                    const uint32_t* wrow = reinterpret_cast<const uint32_t*>(OT::tabs.wr[pc ? l : 16]);
+#pragma unroll
+                    for (int k = 0; k < (OT::WR_AFF_RD + AEL + 1) / 2; ++k) otw[k] = wrow[k];
+                }
+                const auto wr_off = [&](int k) { return (k & 1) ? hi16(otw[k >> 1]) : lo16(otw[k >> 1]); };
                 const int64_t wgn = wg0_again() * a.Rn_stride;
                 const TS* Rn = at(a.Rn + wgn, fc * IDX(a.Rn_stride));
                 const TS* Ra = at(a.Racc + wgn, fc * IDX(a.Rn_stride));
-                const bool all_acc = NZ_EARLY && wave_all(pin.use_acc);
-                // affine block entry e = l + 16 t -> (row, column) inside the (D - NL) triangle, from nibble tables
-                // indexed by the lane (entries past the triangle decode to (0, 0) and are not stored)
-                int ar[AEL], ac[AEL];
-                bool av[AEL];
+                // element imm behind byte offset off of the (HBM) noise table
+                const auto rn_off = [&](uint32_t off, int imm) {
+                    return T(reinterpret_cast<const TS*>(reinterpret_cast<const unsigned char*>(Rn) + off)[imm]);
+                };
+                T acc[TR][TC];
 #pragma unroll
-                for (int t = 0; t < AEL; ++t) {
-                    av[t] = l + G * t < NAB;
-                    ar[t] = NL + int((tri_rows(G * t) >> (4 * l)) & 15ull);
-                    ac[t] = NL + int((tri_cols(G * t) >> (4 * l)) & 15ull);
-                }
-                T acc[TR][TC], nz[TR][TC], anz[AEL];
-                {
+                for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                    for (int i2 = 0; i2 < TR; ++i2)
+                    for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = T(0);
+                // Rotated noise (OrientationUKF.cpp:84-85): only the two 3x3 diagonal blocks of the nonlinear 6x6 block are rotated.
+                // Its 21 entries are evaluated ONCE per filter, at most two per lane, and parked in LDS; the tiles pick them up after
+                // the accumulation loop.  Isotropic blocks (noise_plain, the default and every BASELINE configuration) need none of it.
+                if (!noise_plain) {
 #pragma unroll
-                        for (int j2 = 0; j2 < TC; ++j2) acc[i2][j2] = nz[i2][j2] = T(0);
-#pragma unroll
-                    for (int t = 0; t < AEL; ++t) anz[t] = T(0);
-                    if (all_acc) {   // wave-uniform: plain table reads, all in flight together
-#pragma unroll
-                        for (int i2 = 0; i2 < TR; ++i2)
-#pragma unroll
-                            for (int j2 = 0; j2 < TC; ++j2) {
-                                const int r = R0 + i2, c = C0 + j2;
-                                const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                                nz[i2][j2] = T(Ra[rc * D + cc]);
-                            }
-#pragma unroll
-                        for (int t = 0; t < AEL; ++t) anz[t] = T(Ra[ar[t] * D + ac[t]]);
-                    } else {
-                        // Rotated noise (PoseUKF.cpp:184-185, OrientationUKF.cpp:84-85): only the two 3x3 diagonal blocks of
-                        // the nonlinear 6x6 block are rotated.  Its 21 entries are evaluated ONCE per filter, at most two
-                        // per lane, and parked in LDS; the tiles pick them up after the accumulation loop.  (Evaluating the
-                        // rotation for every entry of every tile cost ~200 instructions per wavefront in the Orient cycle.)
-                        if (NZ_EARLY || !noise_plain)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const bool v = l + G * t < NL * (NL + 1) / 2;
-                            const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
-                            // (isotropic blocks, noise_plain: the table entry itself, no rotation and no rotation matrix)
-                            const T ne = (M::MODEL != 0 && noise_plain) ? plain_noise_entry16<T, M>(Rn, Ra, pin, r, c)
-                                                                        : process_noise_entry16<T, M>(Rn, Ra, ROT, pin, r, c);
-                            NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = ne;
-                        }
-                        if constexpr (NZ_EARLY) {   // Pose: fetch this lane's entries now, consume them after the loop
-#pragma unroll
-                            for (int i2 = 0; i2 < TR; ++i2)
-#pragma unroll
-                                for (int j2 = 0; j2 < TC; ++j2) {
-                                    const int r = R0 + i2, c = C0 + j2;
-                                    const int rn_ = is_cross ? 0 : r, cn_ = is_cross ? 0 : c;   // a nonlinear tile: rows / columns < NL
-                                    T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
-                                    keep(shaped);
-                                    const T plain = plain_noise_entry16<T, M>(Rn, Ra, pin, r, c);
-                                    nz[i2][j2] = is_cross ? plain : shaped;
-                                }
-#pragma unroll
-                            for (int t = 0; t < AEL; ++t) anz[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
-                        }
+                    for (int t = 0; t < 2; ++t) {
+                        const bool v = l + G * t < NL * (NL + 1) / 2;
+                        const int r = v ? int((tri_rows(G * t) >> (4 * l)) & 15ull) : 0, c = v ? int((tri_cols(G * t) >> (4 * l)) & 15ull) : 0;
+                        NSH[v ? (l + G * t) : (LY::NSH_SINK - LY::NSH)] = process_noise_entry16<T, M>(Rn, Ra, ROT, pin, r, c);
                     }
                 }
 #pragma unroll
@@ -1481,66 +1517,63 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                 st |= (do_p && !ok) ? ST_ERR_CHOLESKY : 0u;
                 st |= (p_commit && !conv) ? ST_WARN_MEAN_NOCONV : 0u;
                 {
-                    // Orient picks its noise up late: ALL global loads of this lane's entries are issued here, together,
-                    // before anything waits for one of them (issued one by one between the stores below they cost a full
-                    // L2 round trip each: eleven in a row were 20 % of the Orient wavefront's life)
+                    // The noise is picked up late: ALL global loads of this lane's entries are issued here, together, before anything
+                    // waits for one of them (issued one by one between the stores below they cost a full L2 round trip each: eleven
+                    // in a row were 20 % of the wavefront's life).  A tile that hangs over the matrix reads past its table (padded).
+                    const T dt2 = pin.dt * pin.dt;
                     T pl[TR][TC], apl[AEL];
-                    if constexpr (!NZ_EARLY) {
 #pragma unroll
-                        for (int i2 = 0; i2 < TR; ++i2)
+                    for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
-                            for (int j2 = 0; j2 < TC; ++j2) {
-                                const int r = R0 + i2, c = C0 + j2;
-                                const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                                pl[i2][j2] = plain_noise_entry16<T, M>(Rn, Ra, pin, rc, cc);
-                            }
-#pragma unroll
-                        for (int t = 0; t < AEL; ++t) apl[t] = plain_noise_entry16<T, M>(Rn, Ra, pin, ar[t], ac[t]);
-                        sfence();
-                    }
+                        for (int j2 = 0; j2 < TC; ++j2) pl[i2][j2] = dt2 * rn_off(hi16(otr[1]), i2 * D + j2);
+                    apl[0] = dt2 * rn_off(lo16(otr[2]), 0);
+                    apl[1] = dt2 * rn_off(hi16(otr[2]), 0);
+                    sfence();
                     // the two halves of a nonlinear tile sit on neighbouring lanes (xor 1); a cross lane keeps its own sum
                     // (weight 0: its neighbour's accumulators are finite sums of the same filter)
-                    const T wsum = is_cross ? T(0) : T(1);
-                    const bool writer = p_commit && (l < MT<M>::WORK_LANES) && (is_cross || half == 0);
-                    // (OrientationState with isotropic noise blocks: every entry is the plain table value that is already in
-                    // flight, the shaped-noise table is neither filled nor read -- a second copy of the loop under a wave-uniform
-                    // branch, because a branch per entry makes the register allocator spill)
+                    const bool nonlin = (flags & 1u) != 0u;
+                    const T wsum = nonlin ? T(1) : T(0);
+                    // (isotropic noise blocks: every entry is the plain table value that is already in flight, the shaped-noise table
+                    // is neither filled nor read -- a second copy of the loop under a wave-uniform branch, because a branch per entry
+                    // makes the register allocator spill)
                     auto store_tiles = [&](auto plain_c) {
                         constexpr bool PLAIN_NOISE = decltype(plain_c)::value;
+                        int R0 = 0, C0 = 0;
+                        if constexpr (!PLAIN_NOISE) {   // where the shaped entries sit: the tile origin, decoded on this path only
+                            const int lw = (l < MT<M>::WORK_LANES) ? l : 0;
+                            R0 = int((MT<M>::TILE_R >> (4 * lw)) & 15ull);
+                            C0 = int((MT<M>::TILE_C >> (4 * lw)) & 15ull);
+                        }
 #pragma unroll
                         for (int i2 = 0; i2 < TR; ++i2)
 #pragma unroll
                             for (int j2 = 0; j2 < TC; ++j2) {
-                                const int r = R0 + i2, c = C0 + j2;
-                                const bool w = writer && (TILES_INSIDE || r < D) && c <= r;
-                                const int rc = (TILES_INSIDE || r < D) ? r : (D - 1), cc = (TILES_INSIDE || c < D) ? c : (D - 1);
-                                T nv = nz[i2][j2];
-                                if constexpr (!NZ_EARLY) {   // Orient: picked up late (nine values per lane would live across the loop)
-                                    if constexpr (PLAIN_NOISE) {
-                                        nv = pl[i2][j2];
-                                    } else {
-                                        const int rn_ = is_cross ? 0 : rc, cn_ = is_cross ? 0 : cc;   // a nonlinear tile: rows / columns < NL
-                                        T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
-                                        keep(shaped);
-                                        nv = is_cross ? pl[i2][j2] : shaped;
-                                    }
+                                T nv = pl[i2][j2];
+                                if constexpr (!PLAIN_NOISE) {
+                                    const int rn_ = nonlin ? (R0 + i2) : 0, cn_ = nonlin ? (C0 + j2) : 0;   // a nonlinear tile: rows / columns < NL
+                                    T shaped = NSH[rn_ * (rn_ + 1) / 2 + cn_];
+                                    keep(shaped);
+                                    nv = nonlin ? shaped : nv;
                                 }
                                 const T tot = fma(wsum, dpp_mov<0xB1>(acc[i2][j2]), acc[i2][j2]);   // quad_perm [1,0,3,2]
-                                // (idle lanes: the noise table's spare slot -- the table may still be read by the next entries)
-                                PKS[w ? (r * (r + 1) / 2 + c) : (LY::NSH_SINK - LY::PKS)] = tot + nv;
+                                // (entries the lane does not own: the noise table's spare slot -- the table may still be read)
+                                *reinterpret_cast<T*>(wbase + wr_off(OT::WR_TILE + i2 * TC + j2)) = tot + nv;
                             }
                     };
-                    if (!NZ_EARLY && noise_plain) store_tiles(std::true_type{});
+                    if (noise_plain) store_tiles(std::true_type{});
                     else store_tiles(std::false_type{});
-                    // affine block in place: the old entries are still staged
+                    // affine block in place: the old entries are still staged; scale classes of row and column from the flags
+                    const T sg = MT<M>::aff_scale(NL, pin), sa = MT<M>::aff_scale(NL + 3, pin);
+                    const auto scale_of = [&](int shift) {
+                        const uint32_t cls = (flags >> shift) & 3u;
+                        return (cls == 0u) ? sg : ((cls == 1u) ? sa : T(1));
+                    };
 #pragma unroll
                     for (int t = 0; t < AEL; ++t) {
-                        const int idx = ar[t] * (ar[t] + 1) / 2 + ac[t];
-                        T old = PKS[idx];
+                        T old = *reinterpret_cast<const T*>(wbase + wr_off(OT::WR_AFF_RD + t));
                         keep(old);
-                        const T nv = NZ_EARLY ? anz[t] : apl[t];
-                        const T ss = (M::MODEL == 0) ? T(1) : MT<M>::aff_scale(ar[t], pin) * MT<M>::aff_scale(ac[t], pin);
-                        PKS[(p_commit && av[t]) ? idx : (LY::DUM - LY::PKS)] = fma(ss, old, nv);
+                        const T ss = scale_of(2 + 4 * t) * scale_of(4 + 4 * t);
+                        *reinterpret_cast<T*>(wbase + wr_off(OT::WR_AFF + t)) = fma(ss, old, apl[t]);
                     }
                 }
             }

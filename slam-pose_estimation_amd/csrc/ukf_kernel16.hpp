@@ -200,8 +200,9 @@ template <class T> struct MT<OrientM<T>> {
     }
     // velocityMeasurementModel (OrientationUKF.cpp:34-39): q.inverse() * v for the three sigma points;
     // the velocity (stored 4..6, tangent 3..5) comes straight from the mean staging and the factor column
-    UKFB_DEV static void body_vel(const T (&q)[4], const T (&v)[3], T (&z)[4]) {
-        const T rn = fast_rcp(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    // (rn = 1 / |q|^2, passed in: the three sigma-point orientations of a lane are q0 times unit exponentials -- one reciprocal of
+    // |q0|^2 serves all of them, to the rounding of the exponential's norm)
+    UKFB_DEV static void body_vel(const T (&q)[4], const T (&v)[3], T rn, T (&z)[4]) {
         const T qi[4] = {-q[0] * rn, -q[1] * rn, -q[2] * rn, q[3] * rn};
         T r[3];
         quat_rotate(qi, v, r);
@@ -213,9 +214,10 @@ template <class T> struct MT<OrientM<T>> {
         const T cv[3] = {colp[3] * w, colp[4] * w, colp[5] * w};
         const T vp[3] = {v0[0] + cv[0], v0[1] + cv[1], v0[2] + cv[2]};
         const T vm[3] = {v0[0] - cv[0], v0[1] - cv[1], v0[2] - cv[2]};
-        body_vel(qp, vp, zp);
-        body_vel(qm, vm, zm);
-        body_vel(q0, v0, z0);
+        const T rn = fast_rcp(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+        body_vel(qp, vp, rn, zp);
+        body_vel(qm, vm, rn, zm);
+        body_vel(q0, v0, rn, z0);
     }
 };
 

@@ -20,8 +20,30 @@ template <class T, class M> static void dump(const char* name, bool last) {
     }
     std::printf("]}%s\n", last ? "" : ",");
 }
+// the OrientationState kernels' 16-bit tables (OCovTab)
+template <class T, class M> static void dump_o(const char* name) {
+    using OT = ukfb::OCovTab<T, M>;
+    using LY = ukfb::Layout16<T, M>;
+    constexpr auto t = OT::make();
+    std::printf("\"%s\": {\"SZ\": %d, \"D\": %d, \"NL\": %d, \"TR\": %d, \"TC\": %d, \"AEL\": %d, \"PKS\": %d, \"DUM\": %d, \"NSH_SINK\": %d, \"TNL\": %d, \"LAF\": %d, \"ST\": %d, \"TRIP\": %d, \"NRD\": %d, \"NWR\": %d,\n \"rd\": [",
+                name, OT::SZ, OT::D, OT::NL, OT::TR, OT::TC, OT::AEL, LY::PKS, LY::DUM, LY::NSH_SINK, LY::TNL, LY::LAF, LY::ST, LY::TRIP, OT::NRD, OT::NWR);
+    for (int l = 0; l < 16; ++l) {
+        std::printf("%s[", l ? ", " : "");
+        for (int k = 0; k < OT::NRD; ++k) std::printf("%s%u", k ? ", " : "", unsigned(t.rd[l][k]));
+        std::printf("]");
+    }
+    std::printf("],\n \"wr\": [");
+    for (int l = 0; l < 17; ++l) {
+        std::printf("%s[", l ? ", " : "");
+        for (int k = 0; k < OT::NWR; ++k) std::printf("%s%u", k ? ", " : "", unsigned(t.wr[l][k]));
+        std::printf("]");
+    }
+    std::printf("]},\n");
+}
 int main() {
     std::printf("{\n");
+    dump_o<double, ukfb::OrientM<double>>("orient_f64_o");
+    dump_o<float, ukfb::OrientM<float>>("orient_f32_o");
     dump<double, ukfb::PoseM<double>>("pose_f64", false);
     dump<float, ukfb::PoseM<float>>("pose_f32", false);
     dump<float, ukfb::OrientM<float>>("orient_f32", false);

@@ -86,13 +86,15 @@ def pose_scenario(rng, k, fails):
         cov[i] *= overall[i]
         cov[i, 3:6, :] *= np.sqrt(rot[i]); cov[i, :, 3:6] *= np.sqrt(rot[i])
     mu[:, 10:13] *= 10.0 ** rng.uniform(-1, 1.5, (n, 1))                   # spin up to ~6 rad/s
-    ctx = f"pose k={k} n={n} prec={'f64' if prec == 0 else 'f32'}"
+    # (a third of the fp32 scenarios run the wide-arithmetic mode: fp32 arrays, fp64 arithmetic -- same tolerance, same oracle)
+    wide = {"wide_arithmetic": 1} if (prec == 1 and rng.integers(0, 3) == 0 and os.environ.get("UKFB_FUZZ_NO_WIDE") != "1") else {}
+    ctx = f"pose k={k} n={n} prec={'f64' if prec == 0 else ('f32-wide' if wide else 'f32')}"
     R = spe.synth.pose_default_process_noise() * 10.0 ** rng.uniform(-2, 1)
     if rng.uniform() < 0.5:
         R = aniso(rng, R)
     acc_cov = np.eye(3) * 10.0 ** rng.uniform(-4, -1)
-    eng = spe.BatchPoseUKF(n, precision=prec)
-    fused = spe.BatchPoseUKF(n, precision=prec)
+    eng = spe.BatchPoseUKF(n, precision=prec, **wide)
+    fused = spe.BatchPoseUKF(n, precision=prec, **wide)
     gate = float(rng.choice([-1.0, -1.0, 6.0]))
     cfg = oracle.default_config(gate_chi2=gate)
     for e in (eng, fused):
@@ -161,14 +163,15 @@ def orient_scenario(rng, k, fails):
     for i in range(n):
         cov[i] *= overall[i]
         cov[i, 0:3, :] *= np.sqrt(rot[i]); cov[i, :, 0:3] *= np.sqrt(rot[i])
-    ctx = f"orient k={k} n={n} prec={'f64' if prec == 0 else 'f32'}"
+    wide = {"wide_arithmetic": 1} if (prec == 1 and rng.integers(0, 3) == 0 and os.environ.get("UKFB_FUZZ_NO_WIDE") != "1") else {}
+    ctx = f"orient k={k} n={n} prec={'f64' if prec == 0 else ('f32-wide' if wide else 'f32')}"
     R = s.orient_process_noise() * 10.0 ** rng.uniform(-1, 2)
     if rng.uniform() < 0.5:
         R = aniso(rng, R)
     tau_g, tau_a = float(10.0 ** rng.uniform(1, 4)), float(10.0 ** rng.uniform(1, 4))
-    eng = spe.BatchOrientationUKF(n, tau_g, tau_a, s.ORIENT_LATITUDE, precision=prec)
+    eng = spe.BatchOrientationUKF(n, tau_g, tau_a, s.ORIENT_LATITUDE, precision=prec, **wide)
     eng.initialize(mu, cov); eng.set_process_noise(R)
-    fused = spe.BatchOrientationUKF(n, tau_g, tau_a, s.ORIENT_LATITUDE, precision=prec)
+    fused = spe.BatchOrientationUKF(n, tau_g, tau_a, s.ORIENT_LATITUDE, precision=prec, **wide)
     fused.initialize(mu, cov); fused.set_process_noise(R)
     m_o, c_o = mu.copy(), cov.copy()
     m_f, c_f = mu.copy(), cov.copy()

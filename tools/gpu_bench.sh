@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the reference bench lines of a build (short, default and fp32), compact summary on stdout.
-out=gpurun_out/r03_$1; mkdir -p $out; shift
+out=gpurun_out/${UKFB_ROUND:-r04}_$1; mkdir -p $out; shift
 export TMPDIR=/tmp
 run() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > $out/$name.json 2> $out/$name.err || tail -3 $out/$name.err;
   python3 - $out/$name.json $name <<'PY'
@@ -30,6 +30,8 @@ for what in "$@"; do
     f64_1000) run f64_1000 --no-cpu-baseline --steps 1000 --no-extra-regions ;;
     track_1000) run track_1000 --no-cpu-baseline --steps 1000 --no-extra-regions --inputs tracking ;;
     group2) run group2 --no-cpu-baseline --launcher group --gpus 2 --group-devices 0,0 ;;
+    cfg3w) run cfg3w --no-cpu-baseline --precision f32 --wide-arithmetic 1 ;;
+    cfg4w) run cfg4w --no-cpu-baseline --workload orient --precision f32 --filters 4194304 --wide-arithmetic 1 ;;
     full) run full ;;
     cabi) make -s -C tests/cpp build/cabi_bench 2>/dev/null; for a in "1048576 500 f64" "1048576 500 f32" "131072 500 f64" "1048576 500 f64 2"; do tests/cpp/build/cabi_bench $a | tee -a $out/cabi.txt; done ;;
   esac

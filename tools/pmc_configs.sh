@@ -10,7 +10,7 @@
 #        about 25 -- run parts 1 and 2 in two calls (their outputs merge in gpurun_out/pmc_configs) and then
 #        `python3 tools/pmc_report.py gpurun_out/pmc_configs <tag>` in the container; copy the json / csv files into profiles/
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 part=${2:-all}
 out=$PWD/gpurun_out/pmc_configs; mkdir -p $out
 export TMPDIR=/tmp
@@ -47,6 +47,8 @@ if [ $part = 1 ]; then exit 0; fi
 cfg cfg4 --workload orient --precision f32 --filters 4194304
 cfg cfg5 --workload pose-mixed --filters 262144
 cfg multi8_f32 --cycles-per-launch 8 --warmup 16 --precision f32
+cfg wide_f32 --precision f32 --wide-arithmetic 1
+cfg cfg4_wide --workload orient --precision f32 --filters 4194304 --wide-arithmetic 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions --filters 65536 --split-streams 0 > $out/trace_cfg2.json 2> $out/trace_cfg2.err
 # kernel stats of the default command (the driver's own invocation and the 500-step default)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-extra-regions > $out/trace_default.json 2> $out/trace_default.err

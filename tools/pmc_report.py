@@ -46,13 +46,13 @@ for prec in ("f64", "f32"):
     calib[prec] = {"known_bytes": known, "FETCH_SIZE_bytes": fc, "WRITE_SIZE_bytes": wc, "k_read": known / fc, "k_write": known / wc}
 
 traffic, pmc, lines = [], [], []
-for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "multi8_f64", "multi8_f32"):
+for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "multi8_f64", "multi8_f32", "wide_f32", "cfg4_wide"):
     try:
         bench = json.loads(open(os.path.join(out, f"{name}_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     except Exception as e:
         lines.append(f"{name}: no bench line ({e})")
         continue
-    prec = bench["dtype"]
+    prec = bench["config"].get("hbm_format", bench["dtype"])   # (wide arithmetic: fp32 arrays, dtype f64)
     kern = bench["roofline"]["kernel"]
     n = bench["config"]["filters_per_gpu"]
     fetch = mean_counter(f"{name}_FETCH_SIZE", "FETCH_SIZE", "ukf_kernel") * 1024.0

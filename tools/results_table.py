@@ -2,11 +2,11 @@
 """Prints the rows of BASELINE.md's results table from the end-of-round bench lines of a build
 (profiles/<prefix>_*.json, written by tools/gpu_bench.sh end ...): filter-cycles/s, HBM GB/s = the line's PMC traffic over its
 kernel time, roofline.achieved fraction, CPU oracle, largest error against the oracle replay.
-usage: tools/results_table.py [prefix=profiles/r03_final]"""
+usage: tools/results_table.py [prefix=profiles/r04_final]"""
 import json
 import sys
 
-prefix = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03_final"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_final"
 
 
 def line(name):
@@ -39,6 +39,8 @@ row("3: 1 048 576 Pose (one GPU: all of it)", "fp32", "1", "f32", f32_err("f32")
 row("3: one GPU's share at N = 8 (131 072 Pose)", "fp32", "1 of 8", "cfg3", "as above")
 row("metric: one GPU's share at N = 8 (131 072 Pose)", "fp64", "1 of 8", "shard8")
 row("4: 4 194 304 Orient", "fp32", "1", "cfg4", f32_err("cfg4"))
+row("3 with `wide_arithmetic` (fp32 arrays, fp64 arithmetic)", "fp32 / fp64", "1", "cfg3w")
+row("4 with `wide_arithmetic`", "fp32 / fp64", "1", "cfg4w")
 row("5: 262 144 Pose mixed", "fp64", "1", "cfg5")
 row("metric: 1 048 576 Pose (headline, `python bench.py`)", "fp64", "1", "full")
 row("the same, the driver's `--steps 20 --warmup 5`", "fp64", "1", "f64_20")

@@ -32,6 +32,7 @@ for what in "$@"; do
     group2) run group2 --no-cpu-baseline --launcher group --gpus 2 --group-devices 0,0 ;;
     cfg3w) run cfg3w --no-cpu-baseline --precision f32 --wide-arithmetic 1 ;;
     cfg4w) run cfg4w --no-cpu-baseline --workload orient --precision f32 --filters 4194304 --wide-arithmetic 1 ;;
+    uni262k) run uni262k --no-cpu-baseline --filters 262144 ;;
     full) run full ;;
     cabi) make -s -C tests/cpp build/cabi_bench 2>/dev/null; for a in "1048576 500 f64" "1048576 500 f32" "131072 500 f64" "1048576 500 f64 2"; do tests/cpp/build/cabi_bench $a | tee -a $out/cabi.txt; done ;;
   esac

@@ -52,7 +52,8 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "mu
     except Exception as e:
         lines.append(f"{name}: no bench line ({e})")
         continue
-    prec = bench["config"].get("hbm_format", bench["dtype"])   # (wide arithmetic: fp32 arrays, dtype f64)
+    prec = bench["config"].get("hbm_format", bench["dtype"])   # HBM format (wide arithmetic: fp32 arrays, dtype f64)
+    arith = bench["dtype"]                                      # what the instructions are
     kern = bench["roofline"]["kernel"]
     n = bench["config"]["filters_per_gpu"]
     fetch = mean_counter(f"{name}_FETCH_SIZE", "FETCH_SIZE", "ukf_kernel") * 1024.0
@@ -90,7 +91,7 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "mu
         fp32 = cls["FMA_F32"] + cls["MUL_F32"] + cls["ADD_F32"]
         fp64 = cls["FMA_F64"] + cls["MUL_F64"] + cls["ADD_F64"]
         other = per_wave - fp32 - fp64 - cls["TRANS_F32"] - cls["TRANS_F64"] - cls["INT32"] - cls["INT64"] - cls["CVT"]
-        dpp_fused = DPP_FUSED_F32.get(kern, 0.0) if prec == "f32" else 0.0    # counted as FMA / ADD by the SQ, issue like fp64
+        dpp_fused = DPP_FUSED_F32.get(kern, 0.0) if arith == "f32" else 0.0    # counted as FMA / ADD by the SQ, issue like fp64
         weighted = (2.0 * fp32 + 2.0 * dpp_fused + 4.0 * fp64 + 6.5 * cls["TRANS_F32"] + 13.0 * cls["TRANS_F64"] + 3.3 * cls["INT32"]
                     + 4.0 * cls["INT64"] + 4.0 * cls["CVT"] + 3.5 * other)
         cls["other(mov,select,compare,dpp mov)"] = other
@@ -101,11 +102,11 @@ for name in ("headline_f64", "headline_f32", "cfg2", "cfg3", "cfg4", "cfg5", "mu
          "valu_insts_per_wave": valu / waves, "lds_insts_per_wave": lds / waves,
          # issue cost of one wave64 VALU instruction on a SIMD (MI355X_MICROARCH.md, cycle constants): fp64 moves 16 lanes
          # per cycle = 4 cycles; fp32 sustains one instruction per 2 cycles when several waves interleave
-         "issue_cycles_per_valu_inst": 4.0 if prec == "f64" else 2.0,
+         "issue_cycles_per_valu_inst": 4.0 if arith == "f64" else 2.0,
          "sq_active_quadcycles_per_inst": act / valu,             # per-wave activity (overlaps between waves of a SIMD)
          "valu_active_cycles_per_wave": 4.0 * act / waves, "wave_cycles_per_wave": 4.0 * wcyc / waves,
          "clock_mhz": clock_mhz, "kernel_ms_in_pass": ns * 1e-6,
-         "valu_issue_frac_in_pass": (valu * (4.0 if prec == "f64" else 2.0)) / (1024 * clock_mhz * 1e6 * ns * 1e-9),
+         "valu_issue_frac_in_pass": (valu * (4.0 if arith == "f64" else 2.0)) / (1024 * clock_mhz * 1e6 * ns * 1e-9),
          "source": f"rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... GRBM_GUI_ACTIVE, tools/pmc_configs.sh ({tag})"}
     pmc.append(e)
     lines.append(f"{name:13s} {kern:34s} n={n:8d} traffic {hbm / 1e9:7.3f} GB/launch (alg {bench['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f}) "

@@ -49,5 +49,5 @@ for n in ("full", "f32", "cfg4", "cfg4_64"):
     d = line(n)
     m = d.get("multi_cycle")
     print(f"  {n}: {d['value'] / 1e6:.0f} M per cycle" + (f", {m['filter_cycles_per_s_per_gpu'] / 1e6:.0f} M at {m['cycles_per_launch']} cycles per launch" if m else ""))
-for n in ("f64_1000", "track_1000", "cfg5_order", "cfg2_single", "shard8_single", "group2"):
+for n in ("f64_1000", "cfg5_order", "cfg2_single", "shard8_single", "group2", "uni262k"):
     print(f"  {n}: {line(n)['value'] / 1e6:.0f} M")

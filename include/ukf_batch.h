@@ -128,6 +128,16 @@ typedef struct ukfb_config {
                              * cycles of the bench workloads, and no cheaper mix of precisions holds it (DESIGN.md section 3,
                              * profiles/r04_f32_mixed_ab.txt).  This mode does, at the fp64 engine's rate.  Ignored by fp64
                              * engines; ukfb_set_config refuses it together with lanes_per_filter 32 / 64.                     */
+    int32_t full_update_check; /* 0 (default): in a FUSED cycle without per-filter timestamps / time steps / activity masks / gate (the streams-only and plain kernels) the update
+                             * factorises only the columns of the downdated covariance that applyDelta reads (RT + 3 of them) when
+                             * positive definiteness of that covariance is already established: the filter's prediction was committed
+                             * in the same launch (its input covariance factorised, the predicted one is a Gram matrix + noise), the
+                             * batch-uniform process noise is positive semidefinite (checked on the host when it is set) and the
+                             * sample's measurement covariance is positive definite (checked per filter in the kernel).  Results are
+                             * bit-identical with the complete factorisation; what differs: a covariance that is indefinite through
+                             * ROUNDING alone is reported by the next prediction's factorisation (UKFB_ST_ERR_CHOLESKY there), not by
+                             * this update.  Any wavefront with a filter that does not meet the conditions, every update-only launch
+                             * and every other kernel factorise completely, as ukfom's applyDelta does.  1: always complete.    */
 } ukfb_config;
 
 int ukfb_default_config(ukfb_config* cfg);

@@ -337,7 +337,56 @@ template <class T> __global__ void build_racc_kernel(const T* Rn, T* Racc, int64
     Racc[i] = vel ? T(2) * acc_cov9[(r - 6) * 3 + (c - 6)] : Rn[i];
 }
 
+// Positive semidefinite? -- of the symmetric matrix the kernels use (they read the lower triangle).  Cholesky with a tolerance: a pivot
+// below -tol fails; a pivot within tol must head a column of zeros (a zero direction, e.g. the all-zero default noise).
+bool is_psd(const double* A, int D) {
+    std::vector<double> L(size_t(D) * D, 0.0);
+    double dmax = 0.0;
+    for (int i = 0; i < D; ++i) dmax = std::max(dmax, std::fabs(A[size_t(i) * D + i]));
+    const double tol = 1e-12 * dmax;
+    for (int k = 0; k < D; ++k) {
+        double x = A[size_t(k) * D + k];
+        if (!std::isfinite(x)) return false;
+        for (int j = 0; j < k; ++j) x -= L[size_t(k) * D + j] * L[size_t(k) * D + j];
+        if (x < -tol) return false;
+        const bool zero = x <= tol;
+        const double d = zero ? 0.0 : std::sqrt(x);
+        L[size_t(k) * D + k] = d;
+        for (int i = k + 1; i < D; ++i) {
+            double v = A[size_t(i) * D + k];
+            if (!std::isfinite(v)) return false;
+            for (int j = 0; j < k; ++j) v -= L[size_t(i) * D + j] * L[size_t(k) * D + j];
+            if (zero) {
+                if (std::fabs(v) > std::sqrt(tol * std::max(dmax, 1e-300)) + 1e-300) return false;
+                L[size_t(i) * D + k] = 0.0;
+            } else {
+                L[size_t(i) * D + k] = v / d;
+            }
+        }
+    }
+    return true;
+}
+
+// ukfb_config::full_update_check: the host-side condition of the short update factorisation -- the batch-uniform process noise as the
+// prediction adds it (rotation of its diagonal blocks and scaling by dt / dt^2 keep semidefiniteness; Pose acceleration branch: the
+// velocity block replaced by 2 acc.cov, PoseUKF.cpp:190-191) is positive semidefinite
+void refresh_noise_psd(ukfb_engine* e) {
+    if (e->Rn_per_filter || e->Rn_host.size() != size_t(e->D) * e->D) {
+        e->noise_psd = false;
+        return;
+    }
+    bool ok = is_psd(e->Rn_host.data(), e->D);
+    if (ok && e->model == UKFB_MODEL_POSE) {
+        std::vector<double> Ra(e->Rn_host);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Ra[size_t(6 + r) * e->D + (6 + c)] = 2.0 * e->acc_cov[r * 3 + c];
+        ok = is_psd(Ra.data(), e->D);
+    }
+    e->noise_psd = ok;
+}
+
 int rebuild_racc(ukfb_engine* e) {
+    refresh_noise_psd(e);
     if (e->model != UKFB_MODEL_POSE) return UKFB_OK;
     const int64_t nmat = e->Rn_per_filter ? e->cap : 1;
     const size_t dd = size_t(e->D) * e->D;
@@ -715,6 +764,7 @@ int ukfb_default_config(ukfb_config* cfg) {
     cfg->bucket_models = 1;
     cfg->split_streams = 1;
     cfg->wide_arithmetic = 0;
+    cfg->full_update_check = 0;
     return UKFB_OK;
 }
 
@@ -861,6 +911,7 @@ int ukfb_set_config(ukfb_engine* e, const ukfb_config* cfg) {
         return fail(UKFB_ERR_INVALID_ARG, "lanes_per_filter 32 / 64 in fp64 is a diagnostic build option (make GENERIC_F64=1)");
     if (c.mean_max_iter < 1) return fail(UKFB_ERR_INVALID_ARG, "mean_max_iter must be >= 1");
     if (c.wide_arithmetic != 0 && c.wide_arithmetic != 1) return fail(UKFB_ERR_INVALID_ARG, "wide_arithmetic must be 0 or 1");
+    if (c.full_update_check != 0 && c.full_update_check != 1) return fail(UKFB_ERR_INVALID_ARG, "full_update_check must be 0 or 1");
     if (c.wide_arithmetic && e->prec == UKFB_F32 && c.lanes_per_filter != 16)
         return fail(UKFB_ERR_INVALID_ARG, "wide_arithmetic runs on the tuned layout only (lanes_per_filter 16)");
     e->cfg = c;

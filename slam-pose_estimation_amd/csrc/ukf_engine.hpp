@@ -47,6 +47,7 @@ struct ukfb_engine {
     int64_t Racc_mats = 0; // matrices Racc has room for (1, or capacity once the noise is per filter)
     void* acc_cov_dev = nullptr;  // 9 doubles' worth of staging for rebuild_racc (persistent)
     bool Rn_per_filter = false;
+    bool noise_psd = true;   // the batch-uniform process noise (and, Pose, its acceleration-branch form) is positive semidefinite
     bool noise_iso = true;   // rotated diagonal blocks of the (batch-uniform) process noise are s * I; the zero default is
     std::vector<double> Rn_host;  // uniform copy
 

@@ -51,6 +51,7 @@ template <class T> struct KArgs {
     int fidx_inputs;
     int status_accumulate;       // != 0: OR the new status word into the stored one instead of replacing it
     int noise_iso;               // != 0: the two 3x3 diagonal noise blocks that the models rotate are multiples of the identity
+    int upd_short_ok;            // != 0: the host-side conditions of the short update factorisation hold (ukfb_config::full_update_check)
                                  // (batch-uniform noise only) -- R s I R^T = s I, the rotation is skipped (ukf_kernel16.hpp)
     T* mu;                       // [filters][S]
     T* cov;                      // [n][PK] packed lower triangle, row-major

@@ -1886,8 +1886,27 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                     srow2[b] = arow2[b];
                     if constexpr (b >= RT && b < RT + 3) drot[b - RT] = row_bcast<b>(del);   // the rotation part of delta, on every lane
                 });
+                // applyDelta reads the first RT + 3 columns of this factor; the remaining steps exist to find out whether Sigma' is
+                // positive definite at all.  In a fused cycle of the plain kind that is already established when (ukfb_config::
+                // full_update_check) the filter's prediction was committed in THIS launch -- its input covariance factorised, the
+                // predicted one a Gram matrix plus a noise the host found positive semidefinite -- and the sample's measurement
+                // covariance is positive definite: Sigma' = Sigma - K S K^T is then the Schur complement of a positive definite joint
+                // covariance.  Wave-uniform: one filter that does not qualify sends its wavefront through the complete factorisation
+                // (every update-only launch and every other kernel always).  The published columns are the same either way.
+                bool short_fact = false;
+                if constexpr (DO_PREDICT && PLAIN >= 1) {   // (streams-only and plain fused cycles; m = the filter's measurement dimension)
+                    if (a.upd_short_ok != 0) {
+                        const T q00 = ZQ[3], q10 = ZQ[6], q11 = ZQ[7], q20 = ZQ[9], q21 = ZQ[10], q22 = ZQ[11];
+                        const T m2 = fma(q00, q11, -(q10 * q10));
+                        const T det = fma(q22, m2, fma(q20, fma(q10, q21, -(q11 * q20)), -(q21 * fma(q00, q21, -(q10 * q20)))));
+                        // leading minors of the m x m covariance the update uses (the rest of the 3 x 3 is padding)
+                        const bool q_pd = (q00 > T(0)) && (m < 2 || m2 > T(0)) && (m < 3 || det > T(0));
+                        short_fact = wave_all(!do_u || (p_commit && q_pd));
+                    }
+                }
                 UKFB_PRIO(1);
-                rs2 = chol16<T, D, LS, D, RT + 3>(arow2, Lc, l, ok2);   // applyDelta reads the first RT + 3 columns only
+                if (short_fact) rs2 = chol16<T, D, LS, RT + 3, RT + 3>(arow2, Lc, l, ok2);
+                else rs2 = chol16<T, D, LS, D, RT + 3>(arow2, Lc, l, ok2);
                 UKFB_PRIO(0);
                 wsync();
             }

@@ -251,6 +251,7 @@ template <class T, class M> static int launch_typed(ukfb_engine* e, const Launch
     a.Rn = static_cast<const T*>(e->Rn);
     a.Rn_stride = e->Rn_per_filter ? int64_t(M::D) * M::D : 0;
     a.noise_iso = (e->noise_iso && !e->Rn_per_filter) ? 1 : 0;
+    a.upd_short_ok = (e->noise_psd && !e->Rn_per_filter && !e->cfg.full_update_check) ? 1 : 0;
     a.Racc = static_cast<const T*>(e->Racc);
     a.in_a = static_cast<const T*>(e->in_a_bound ? e->in_a_bound : e->in_a);
     a.in_b = static_cast<const T*>(e->in_b_bound ? e->in_b_bound : e->in_b);

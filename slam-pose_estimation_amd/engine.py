@@ -64,7 +64,8 @@ BODY_STATE_SCALARS = 49
 class Config(C.Structure):
     _fields_ = [("mean_tol", C.c_double), ("mean_max_iter", C.c_int32), ("gate_chi2", C.c_double),
                 ("min_time_delta", C.c_double), ("max_time_delta", C.c_double), ("lanes_per_filter", C.c_int32),
-                ("bucket_models", C.c_int32), ("split_streams", C.c_int32), ("wide_arithmetic", C.c_int32)]
+                ("bucket_models", C.c_int32), ("split_streams", C.c_int32), ("wide_arithmetic", C.c_int32),
+                ("full_update_check", C.c_int32)]
 
 
 class UkfbError(RuntimeError):

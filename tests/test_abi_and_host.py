@@ -55,6 +55,7 @@ def test_default_config_matches_reference_defaults(spe):
     assert c.max_time_delta == np.finfo(np.float64).max   # UnscentedKalmanFilter.hpp:32
     assert c.gate_chi2 < 0                         # accept_any_mahalanobis_distance
     assert c.lanes_per_filter == 16
+    assert c.wide_arithmetic == 0 and c.full_update_check == 0 and c.split_streams == 1 and c.bucket_models == 1
     # ukfom's iteration cap, and the CPU oracle's (oracle/ukf_oracle.hpp:78): the engine must not give up earlier
     from oracle import capi
     assert c.mean_max_iter == 10000 == capi.default_config().mean_max_it

@@ -146,6 +146,122 @@ def test_plain_levels_of_separate_predict_and_update_launches(spe, prec):
     assert (st1[5] & spe.ST_ERR_CHOLESKY) and (st1[n - 1] & spe.ST_UNINITIALISED)
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("model", ["pose", "orient"])
+def test_short_update_factorisation_is_the_complete_one_where_it_is_taken(spe, oracle, prec, model):
+    """ukfb_config.full_update_check = 0 (default): a fused plain cycle factorises only the RT + 3 columns of the downdated covariance
+    that applyDelta reads when that covariance is positive definite by construction (prediction committed in the same launch, process
+    noise positive semidefinite -- host check --, measurement covariance positive definite -- per-filter check).  Same bits and same
+    status words as full_update_check = 1 over several cycles, including a filter whose input covariance is indefinite (its prediction
+    is refused: the wavefront takes the complete factorisation), a filter whose sample carries an INDEFINITE measurement covariance
+    (likewise; the status is the oracle's) and an engine whose process noise is not positive semidefinite (the host switches the short
+    form off).  ukfom's applyDelta always factorises completely."""
+    import torch
+    s = spe.synth
+    n = 4099
+    tdt = torch.float64 if prec == 0 else torch.float32
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x.reshape(x.shape[0], -1))).to("cuda", tdt)   # noqa: E731
+    if model == "pose":
+        mu, cov = s.pose_initial(n)
+        acc, z, Q = s.pose_cycle_inputs(n, 0, mu[:, :3], random_q=True)
+        noise = s.pose_default_process_noise()
+    else:
+        mu, cov = s.orient_initial(n)
+        gyro, acc, z, Q = s.orient_cycle_inputs(n, 0, mu[:, :4])
+        noise = s.orient_process_noise()
+    cov[5] = -cov[5]                                      # prediction refused -> no update of a verified covariance
+    Q = Q.copy()
+    Q[9] = np.diag([0.01, -0.5, 0.01])                    # an indefinite measurement covariance
+    z_t, Q_t, a_t = dev(z), dev(Q), dev(acc)
+    g_t = dev(gyro) if model == "orient" else None
+    torch.cuda.synchronize()
+
+    def run(full, bad_noise=False):
+        if model == "pose":
+            e = spe.BatchPoseUKF(n, precision=prec, stream="private", full_update_check=full)
+            e.set_acceleration(None, 0.01 * np.eye(3))
+        else:
+            e = spe.BatchOrientationUKF(n, s.ORIENT_TAU, s.ORIENT_TAU, s.ORIENT_LATITUDE, precision=prec, stream="private", full_update_check=full)
+        R = noise.copy()
+        if bad_noise:
+            R[7, 7] = -1e-9                               # not positive semidefinite: the host keeps the complete factorisation
+        e.set_process_noise(R)
+        e.initialize(mu, cov)
+        if model == "pose":
+            e.bind_acceleration_dev(a_t)
+        else:
+            e.bind_orient_inputs_dev(g_t, a_t)
+        sts = []
+        for _ in range(3):
+            e.cycle_dev(0.01, spe.MEAS_POS3 if model == "pose" else spe.MEAS_ORIENT_BODYVEL3, z_t, Q_t)
+            sts.append(e.status().copy())
+        name = e.last_launch_info()["kernel"]
+        m, c, _ = e.state()
+        e.close()
+        return m, c, sts, name
+
+    m0, c0, st0, k0 = run(0)
+    m1, c1, st1, k1 = run(1)
+    assert k0 == k1 and k0.endswith("cycle-plain>")
+    assert np.array_equal(m0, m1, equal_nan=True) and np.array_equal(c0, c1, equal_nan=True)
+    assert all((a == b).all() for a, b in zip(st0, st1))
+    assert st0[0][5] & spe.ST_ERR_CHOLESKY and st0[0][6] == 0
+    # the filter with the indefinite measurement covariance: whatever the complete factorisation says (the oracle agrees)
+    if model == "pose":
+        mo, co, s1 = oracle.pose_predict(mu[8:12], cov[8:12], noise, acc[8:12], 0.01 * np.eye(3), 0.01)
+        mo, co, s2 = oracle.pose_update(mo, co, spe.MEAS_POS3, z[8:12], Q[8:12])
+        assert (st0[0][8:12] == (s1 | s2)).all()
+    mb0, cb0, stb0, _ = run(0, bad_noise=True)
+    mb1, cb1, stb1, _ = run(1, bad_noise=True)
+    assert np.array_equal(mb0, mb1, equal_nan=True) and np.array_equal(cb0, cb1, equal_nan=True) and all((a == b).all() for a, b in zip(stb0, stb1))
+
+
+@pytest.mark.parametrize("n", [4099, 20_011])      # filter order (streams-only kernel) / bucketed by update class
+def test_short_update_factorisation_with_per_filter_models(spe, oracle, n):
+    """The same for the streams-only kernels: per-filter measurement models (nine models, a quarter of the filters idle, measurement
+    covariances whose unused trailing dimensions are padding), in filter order and bucketed -- full_update_check 0 and 1 give the same
+    bits and status words, and both agree with the oracle."""
+    import torch
+    s = spe.synth
+    mu, cov = s.pose_initial(n)
+    cov[7] = -cov[7]
+    acc, z, Q = s.pose_cycle_inputs(n, 0, mu[:, :3], random_q=True)
+    models = s.pose_mixed_models(n, 0)
+    zm = s.pose_measurement_for_model(mu, models, z - mu[:, :3])
+    for i in np.nonzero((models == spe.MEAS_POS_Z) | (models == spe.MEAS_VEL_XY))[0][:50]:
+        Q[i, 2, 2] = -1.0                                   # padding of a 1- or 2-dimensional measurement: must not matter
+    dev = lambda x, t=torch.float64: torch.from_numpy(np.ascontiguousarray(x.reshape(x.shape[0], -1))).to("cuda", t)   # noqa: E731
+    z_t, Q_t, a_t = dev(zm), dev(Q), dev(acc)
+    m_t = torch.from_numpy(models).to("cuda")
+    torch.cuda.synchronize()
+
+    def run(full):
+        e = spe.BatchPoseUKF(n, stream="private", full_update_check=full)
+        e.set_acceleration(None, 0.01 * np.eye(3))
+        e.initialize(mu, cov)
+        e.bind_acceleration_dev(a_t)
+        for _ in range(2):
+            e.cycle_dev(0.01, 0, z_t, Q_t, meas_model_dev=m_t)
+        name = e.last_launch_info()["kernel"]
+        m, c, _ = e.state()
+        st = e.status()
+        e.close()
+        return m, c, st, name
+
+    m0, c0, st0, k0 = run(0)
+    m1, c1, st1, k1 = run(1)
+    assert k0 == k1 and k0.endswith("cycle-bucketed-streams>" if n >= 16384 else "cycle-streams>")
+    assert np.array_equal(m0, m1, equal_nan=True) and np.array_equal(c0, c1, equal_nan=True) and (st0 == st1).all()
+    R = s.pose_default_process_noise()
+    mo, co = mu[:512], cov[:512]
+    for _ in range(2):
+        mo2, co2, s1 = oracle.pose_predict(mo, co, R, acc[:512], 0.01 * np.eye(3), 0.01)
+        mo, co = np.where((s1 == 0)[:, None], mo2, mo), np.where((s1 == 0)[:, None, None], co2, co)
+        mo, co, s2 = oracle.pose_update(mo, co, models[:512], zm[:512], Q[:512])
+    ok = np.ones(512, dtype=bool); ok[7] = False
+    assert np.abs(m0[:512][ok] - mo[ok]).max() <= 1e-9 and np.abs(c0[:512][ok] - co[ok]).max() <= 1e-9
+
+
 def test_launches_that_do_not_qualify_keep_the_general_kernel(spe):
     import torch
     s = spe.synth

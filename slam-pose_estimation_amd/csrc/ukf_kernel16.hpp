@@ -1204,6 +1204,16 @@ __global__ void __launch_bounds__(64, (waves16<T, M, MULTI>())) ukf_kernel16(con
                         n2 += md[c] * md[c];
                     }
                 }
+#if defined(UKFB_COUNTS)
+                {   // size of the first mean delta's rotation part, largest of the wavefront's committing filters: bin b = |.| in (1e-(8-b), 1e-(7-b)], bin 0 = up to 1e-7
+                    const T a2d = md[RT] * md[RT] + md[RT + 1] * md[RT + 1] + md[RT + 2] * md[RT + 2];
+                    const double thr[7] = {1e-14, 1e-12, 1e-10, 1e-8, 1e-6, 1e-4, 1e-2};
+                    int bin = 0;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) bin += wave_any(pc && double(a2d) > thr[k]) ? 1 : 0;
+                    UKFB_COUNT_VAL(3, bin);
+                }
+#endif
                 // reference [+] mean delta
                 {
                     const T qr[4] = {ref[Q], ref[Q + 1], ref[Q + 2], ref[Q + 3]};

@@ -8,7 +8,8 @@ usage: UKFB_LIB=slam-pose_estimation_amd/lib/ab/stamps.so python3 tools/phase_st
 
 With a -DUKFB_COUNTS build and --counts as LAST argument (tools/build_variant.sh counts -DUKFB_COUNTS): per launch, the histogram over
 wavefronts of the manifold-mean trip counts (slot0: wave trips of the iteration loop = max over the wavefront's four filters;
-slot1: iterations of one filter incl. the first; slot2: final deltas re-based (1) or by a third round of logarithms (0)) and how
+slot1: iterations of one filter incl. the first; slot2: final deltas re-based (1) or by a third round of logarithms (0); slot3: size of the first mean delta's rotation part,
+largest of the wavefront -- bin b = (1e-(8-b), 1e-(7-b)] rad, bin 0 = up to 1e-7) and how
 many of the wavefront-level exp / log calls took their wide-angle paths (dbg = exp calls, exp angle-doubling, exp mod-2pi,
 log_n calls, log_n half-angle path, log calls, log half-angle path)."""
 import torch  # noqa: F401

@@ -566,7 +566,7 @@ __global__ void events_gather_kernel(const int64_t* filt, const int64_t* ts, con
 // filter capacity the tests exercise; every scatter block re-summing all of them was quadratic in the batch size), (3) every
 // block scatters from its offsets.  The
 // classes follow each other from the most expensive to the cheapest, each
-// starts at a multiple of 4 (one wavefront = 4 filters); the list was pre-filled with -1, so the gaps read as padding.
+// starts at a multiple of 4 (one wavefront = 4 filters); the gaps behind the classes are filled with -1 (padding) by the scatter kernel.
 constexpr int BK_THREADS = 256, BK_PER_THREAD = 4, BK_BLOCK = BK_THREADS * BK_PER_THREAD;
 __global__ void __launch_bounds__(BK_THREADS) bucket_count_kernel(const int32_t* meas, int64_t n, int engine_model, uint32_t* counts,
                                                                   int nblocks) {
@@ -616,18 +616,62 @@ __global__ void __launch_bounds__(BS_THREADS) bucket_scan_kernel(const uint32_t*
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(BK_THREADS) bucket_scatter_kernel(const int32_t* meas, int64_t n, int engine_model,
+// INLINE_SCAN (launches of up to BUCKET_INLINE_BLOCKS blocks): every block sums the per-block counts itself -- its own exclusive
+// prefix and the class totals, 3 x nblocks values -- instead of reading them from bucket_scan_kernel's output: one launch fewer
+// where the launches, not the sums, are what the grouping costs (four launches of ~5 us each per cycle at 262 144 filters were 6.6 %
+// of config 5's cycle).  Block 0 also writes the padding (-1) behind each class and up to `items`: no memset of the list.
+template <bool INLINE_SCAN>
+__global__ void __launch_bounds__(BK_THREADS) bucket_scatter_kernel(const int32_t* meas, int64_t n, int engine_model, const uint32_t* counts,
                                                                     const uint32_t* before, const uint32_t* total, int nblocks,
-                                                                    int32_t* order) {
+                                                                    int32_t* order, uint32_t items) {
     using Scan = hipcub::BlockScan<uint32_t, BK_THREADS>;
+    using Reduce64 = hipcub::BlockReduce<unsigned long long, BK_THREADS>;
     __shared__ typename Scan::TempStorage stmp;
+    __shared__ typename Reduce64::TempStorage rtmp;
     __shared__ uint32_t start[3];
-    if (threadIdx.x == 0) {
-        // the most expensive class first: the cheap wavefronts fill the tail of the launch
-        const uint32_t b1 = (total[2] + 3u) & ~3u, b0 = b1 + ((total[1] + 3u) & ~3u);
-        start[2] = before[2 * nblocks + blockIdx.x];
-        start[1] = b1 + before[nblocks + blockIdx.x];
-        start[0] = b0 + before[blockIdx.x];
+    if constexpr (INLINE_SCAN) {
+        __shared__ uint32_t pre_s[3], tot_s[3];
+        for (int c = 0; c < 3; ++c) {
+            unsigned long long acc = 0;   // low word: counts of the blocks before this one, high word: of all blocks
+            for (int b = int(threadIdx.x); b < nblocks; b += BK_THREADS) {
+                const unsigned long long v = counts[c * nblocks + b];
+                acc += (v << 32) | (b < int(blockIdx.x) ? v : 0ull);
+            }
+            const unsigned long long sum = Reduce64(rtmp).Sum(acc);
+            if (threadIdx.x == 0) {
+                pre_s[c] = uint32_t(sum);
+                tot_s[c] = uint32_t(sum >> 32);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const uint32_t b1 = (tot_s[2] + 3u) & ~3u, b0 = b1 + ((tot_s[1] + 3u) & ~3u);
+            start[2] = pre_s[2];
+            start[1] = b1 + pre_s[1];
+            start[0] = b0 + pre_s[0];
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 16) {   // the gaps behind the three classes (at most 3 + 3 + 12 entries)
+            const uint32_t b1 = (tot_s[2] + 3u) & ~3u, b0 = b1 + ((tot_s[1] + 3u) & ~3u);
+            const uint32_t t = threadIdx.x;
+            if (tot_s[2] + t < b1) order[tot_s[2] + t] = -1;
+            if (b1 + tot_s[1] + t < b0) order[b1 + tot_s[1] + t] = -1;
+            if (b0 + tot_s[0] + t < items) order[b0 + tot_s[0] + t] = -1;
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            // the most expensive class first: the cheap wavefronts fill the tail of the launch
+            const uint32_t b1 = (total[2] + 3u) & ~3u, b0 = b1 + ((total[1] + 3u) & ~3u);
+            start[2] = before[2 * nblocks + blockIdx.x];
+            start[1] = b1 + before[nblocks + blockIdx.x];
+            start[0] = b0 + before[blockIdx.x];
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 16) {
+            const uint32_t b1 = (total[2] + 3u) & ~3u, b0 = b1 + ((total[1] + 3u) & ~3u);
+            const uint32_t t = threadIdx.x;
+            if (total[2] + t < b1) order[total[2] + t] = -1;
+            if (b1 + total[1] + t < b0) order[b1 + total[1] + t] = -1;
+            if (b0 + total[0] + t < items) order[b0 + total[0] + t] = -1;
+        }
     }
     __syncthreads();
     const int64_t base = int64_t(blockIdx.x) * BK_BLOCK + int64_t(threadIdx.x) * BK_PER_THREAD;
@@ -648,6 +692,7 @@ __global__ void __launch_bounds__(BK_THREADS) bucket_scatter_kernel(const int32_
             if (cls[j] == c) order[rank++] = int32_t(base + j);
     }
 }
+constexpr int BUCKET_INLINE_BLOCKS = 2048;   // up to 2 M filters: every scatter block sums 3 x 2048 counts at most
 constexpr int64_t BUCKET_MIN_FILTERS = 16384;
 
 // fills e->bucket_idx for the model ids in meas_dev; *items = entries of the list that a launch must cover (an upper bound
@@ -673,15 +718,22 @@ int build_model_buckets(ukfb_engine* e, const int32_t* meas_dev, int64_t* items)
     }
     uint32_t* const before = e->bucket_counts + size_t(3) * nblocks;
     uint32_t* const total = e->bucket_counts + size_t(6) * nblocks;
-    HIP_TRY(hipMemsetAsync(e->bucket_idx, 0xFF, list * sizeof(int32_t), ukfb::main_stream(e)));
+    *items = (n + 3 + 3 + 3) / 4 * 4;   // sum of three counts each rounded up to 4 <= n + 9, itself rounded up to whole wavefronts
+    // (the gaps of the list -- behind each class, up to *items -- are written by the scatter kernel: no memset)
     hipLaunchKernelGGL(bucket_count_kernel, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model, e->bucket_counts,
                        nblocks);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(BS_THREADS), 0, ukfb::main_stream(e), static_cast<const uint32_t*>(e->bucket_counts),
-                       nblocks, before, total);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model,
-                       static_cast<const uint32_t*>(before), static_cast<const uint32_t*>(total), nblocks, e->bucket_idx);
+    if (nblocks <= BUCKET_INLINE_BLOCKS) {
+        hipLaunchKernelGGL(bucket_scatter_kernel<true>, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model,
+                           static_cast<const uint32_t*>(e->bucket_counts), static_cast<const uint32_t*>(before),
+                           static_cast<const uint32_t*>(total), nblocks, e->bucket_idx, uint32_t(*items));
+    } else {
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(BS_THREADS), 0, ukfb::main_stream(e),
+                           static_cast<const uint32_t*>(e->bucket_counts), nblocks, before, total);
+        hipLaunchKernelGGL(bucket_scatter_kernel<false>, dim3(nblocks), dim3(BK_THREADS), 0, ukfb::main_stream(e), meas_dev, n, e->model,
+                           static_cast<const uint32_t*>(e->bucket_counts), static_cast<const uint32_t*>(before),
+                           static_cast<const uint32_t*>(total), nblocks, e->bucket_idx, uint32_t(*items));
+    }
     HIP_TRY(hipGetLastError());
-    *items = (n + 3 + 3 + 3) / 4 * 4;   // sum of three counts each rounded up to 4 <= n + 9, itself rounded up to whole wavefronts
     return UKFB_OK;
 }
 

@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--no-extra-regions", action="store_true", help="skip the sustained / burst kernel timings")
     ap.add_argument("--clock-warmup-seconds", type=float, default=0.4,
                     help="untimed launches before the W warm-up steps (state restored afterwards) so that the GPU clocks have settled")
+    ap.add_argument("--clock-warmup-cycles", type=int, default=0,
+                    help="> 0: the untimed pre-roll is exactly this many cycles instead of a time span (counter passes: the set of "
+                         "launches a profiler sees must not depend on how fast the box is -- the workload is not stationary)")
     ap.add_argument("--workload", choices=["pose", "pose-cv", "pose-mixed", "orient"], default="pose",
                     help="pose: the headline metric (default). pose-cv: the same without a latched acceleration -- the "
                          "constant-velocity branch of predictionStepImpl (PoseUKF.cpp:195: rotated noise, scaled by dt), "
@@ -566,12 +569,15 @@ def run_rank(args):
     mu_view = torch.as_tensor(_DevArray(mu_ptr, (per, S), ts_), device=dev)
     cov_view = torch.as_tensor(_DevArray(cov_ptr, (per, eng.PK), ts_), device=dev)
     z_track = torch.empty((per, 3), dtype=tdtype, device=dev) if tracking else None
-    if args.clock_warmup_seconds > 0:
+    if args.clock_warmup_seconds > 0 or args.clock_warmup_cycles > 0:
         init_state = (mu_view.clone(), cov_view.clone())
         torch.cuda.synchronize()
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.clock_warmup_seconds:
-            run_cycles(64)
+        pre_done = 0
+        while (pre_done < args.clock_warmup_cycles) if args.clock_warmup_cycles > 0 else (time.perf_counter() - t_pre < args.clock_warmup_seconds):
+            burst = min(64, args.clock_warmup_cycles - pre_done) if args.clock_warmup_cycles > 0 else 64
+            run_cycles(burst)
+            pre_done += burst
             eng.sync()
         mu_view.copy_(init_state[0]); cov_view.copy_(init_state[1])
         torch.cuda.synchronize()

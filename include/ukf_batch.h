@@ -400,6 +400,12 @@ int ukfb_group_last_gather_exchange(const ukfb_group* g);
  * most recent predict/update/cycle call launched (for profiles/ and bench.py) */
 int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capacity, int* lds_bytes,
                           int* filters_per_workgroup, int64_t* grid);
+/* the filter list of the most recent launch that grouped its filters by update class (ukfb_cycle_dev with per-filter
+ * model ids, ukfb_config.bucket_models): *items = entries the launch covered, the first min(capacity, *items) of them
+ * copied to list -- filter indices, class by class (sigma-point updates first, then the linear selections, then the
+ * filters without a sample), every class starting at a multiple of 4, -1 = padding.  UKFB_ERR_INVALID_ARG when no
+ * launch of the engine has been grouped. */
+int ukfb_last_model_groups(ukfb_engine* e, int32_t* list, int64_t capacity, int64_t* items);
 /* HIP-event timing on the engine's stream: begin/end bracket a region, elapsed in ms */
 int ukfb_timer_begin(ukfb_engine* e);
 int ukfb_timer_end(ukfb_engine* e, float* elapsed_ms);

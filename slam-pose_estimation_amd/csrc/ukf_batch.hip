@@ -734,6 +734,7 @@ int build_model_buckets(ukfb_engine* e, const int32_t* meas_dev, int64_t* items)
                            static_cast<const uint32_t*>(total), nblocks, e->bucket_idx, uint32_t(*items));
     }
     HIP_TRY(hipGetLastError());
+    e->bucket_items = *items;
     return UKFB_OK;
 }
 
@@ -1842,6 +1843,19 @@ int ukfb_last_launch_info(const ukfb_engine* e, char* kernel_name, int name_capa
     if (lds_bytes) *lds_bytes = e->last_lds;
     if (filters_per_workgroup) *filters_per_workgroup = e->last_fpw;
     if (grid) *grid = e->last_grid;
+    return UKFB_OK;
+}
+
+int ukfb_last_model_groups(ukfb_engine* e, int32_t* list, int64_t capacity, int64_t* items) {
+    if (!e || !items || (capacity > 0 && !list)) return UKFB_ERR_INVALID_ARG;
+    ON_DEVICE(e->device);
+    *items = e->bucket_items;
+    if (!e->bucket_idx || e->bucket_items == 0) return fail(UKFB_ERR_INVALID_ARG, "no launch of this engine has grouped its filters by update class");
+    const int64_t n = capacity < e->bucket_items ? capacity : e->bucket_items;
+    if (n > 0) {
+        HIP_TRY(hipStreamSynchronize(ukfb::main_stream(e)));
+        HIP_TRY(hipMemcpy(list, e->bucket_idx, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return UKFB_OK;
 }
 

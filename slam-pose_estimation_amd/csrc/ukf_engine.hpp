@@ -87,6 +87,7 @@ struct ukfb_engine {
     // model-class buckets of ukfb_cycle_dev with per-filter model ids: filter list ordered by class, padded to whole
     // wavefronts [cap + 16], and the per-block class counts [3][blocks]
     int32_t* bucket_idx = nullptr;
+    int64_t bucket_items = 0;    // entries of bucket_idx the last grouped launch covered (0: none yet)
     uint32_t* bucket_counts = nullptr;
     // ukfb_process_events: device workspace (grow-only)
     void* ev_dev = nullptr;

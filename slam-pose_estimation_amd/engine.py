@@ -46,6 +46,7 @@ EXPORTS = [
     "ukfb_cycle_schedule_dev", "ukfb_cycle_multi_mixed_dev", "ukfb_update_uniform_q", "ukfb_cycle_uniform_q",
     "ukfb_cycle_uniform_q_dev",
     "ukfb_last_launch_info",
+    "ukfb_last_model_groups",
     "ukfb_timer_begin", "ukfb_timer_end", "ukfb_pose_export_body_states", "ukfb_pose_import_body_states",
     "ukfb_cycle_timestamps", "ukfb_cycle_timestamps_dev", "ukfb_process_events", "ukfb_process_events_dev",
     # device groups (one process, several GPUs)
@@ -440,6 +441,15 @@ class BatchUKF:
              "ukfb_last_launch_info")
         return {"kernel": name.value.decode(), "lds_bytes": lds.value, "filters_per_workgroup": fpw.value,
                 "grid": grid.value}
+
+    def last_model_groups(self):
+        """int32 list of the most recent launch that grouped its filters by update class (-1 = padding); see ukf_batch.h"""
+        items = C.c_int64(0)
+        cap = int(self.capacity) + 16
+        out = np.empty(cap, dtype=np.int32)
+        _chk(self._lib.ukfb_last_model_groups(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(cap), C.byref(items)),
+             "ukfb_last_model_groups")
+        return out[:int(items.value)].copy()
 
     def timer_begin(self):
         _chk(self._lib.ukfb_timer_begin(self._h), "ukfb_timer_begin")

@@ -307,6 +307,50 @@ def test_randomised_scenarios_against_the_oracle():
     assert fz.LAUNCHES[0] > 400 and 0 < fz.WORST[0] < 1 and 0 < fz.WORST[1] < 1
 
 
+def test_model_groups_list_is_a_stable_partition(spe):
+    """The list a grouped launch runs over (ukfb_last_model_groups): every filter exactly once, classes in the order sigma-point /
+    linear selection / no sample, every class starting at a multiple of 4 and in ascending filter order (a stable partition), -1
+    in the gaps and nowhere else -- for the path where every scatter block sums the per-block counts itself (up to 2 048 blocks of
+    1 024 filters), for the one with the scan kernel in between (more blocks), and on the SECOND cycle of an engine, whose list
+    still holds the first cycle's entries (the gaps are rewritten, nothing is memset)."""
+    import torch
+    s = spe.synth
+    for n in (16_384, 20_011, 262_144, 2_097_152 + 5_000):
+        eng = spe.BatchPoseUKF(n, precision=spe.F32)
+        CH = 262_144
+        for lo in range(0, n, CH):
+            hi = min(n, lo + CH)
+            mu, cov = s.pose_initial(hi - lo, first=lo)
+            eng.initialize(mu, cov, first=lo)
+        eng.set_acceleration(None, 0.01 * np.eye(3))
+        z_t = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        Q_t = torch.eye(3, dtype=torch.float32, device="cuda").reshape(1, 9).repeat(n, 1).contiguous()
+        a_t = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        eng.bind_acceleration_dev(a_t)
+        for cyc in range(2):
+            models = np.concatenate([s.pose_mixed_models(min(CH, n - lo), cyc, first=lo) for lo in range(0, n, CH)])
+            if cyc == 1:
+                models[models == spe.MEAS_ORIENT_SO3] = 0          # a class that shrinks to nothing: its old entries must not survive
+                models[:5] = spe.MEAS_ORIENT_SO3                      # ... except five filters (a gap of three behind them)
+            m_t = torch.from_numpy(models).cuda()
+            torch.cuda.synchronize()
+            eng.cycle_dev(0.01, spe.MEAS_POS3, z_t, Q_t, meas_model_dev=m_t)
+            eng.sync()
+            assert "bucketed" in eng.last_launch_info()["kernel"]
+            lst = eng.last_model_groups()
+            cls = np.where(models < 0, 0, np.where(models == spe.MEAS_ORIENT_SO3, 2, 1))
+            want = []
+            for c in (2, 1, 0):
+                idx = np.nonzero(cls == c)[0].astype(np.int32)
+                pad = (-len(idx)) % 4
+                want.append(np.concatenate([idx, np.full(pad, -1, dtype=np.int32)]))
+            want = np.concatenate(want)
+            assert len(lst) == (n + 9) // 4 * 4 and len(want) <= len(lst)
+            assert (lst[:len(want)] == want).all(), (n, cyc, np.nonzero(lst[:len(want)] != want)[0][:5])
+            assert (lst[len(want):] == -1).all()
+        eng.close()
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_model_buckets_equal_filter_order(spe, oracle, prec):
     """ukfb_cycle_dev with per-filter model ids groups the filters by the class of their update (none / linear selection /

@@ -23,7 +23,10 @@ for prec in f64 f32; do
 done
 rm -f $out/calib_traffic
 fi
-B="--steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-extra-regions"
+# (a fixed pre-roll of 384 cycles instead of bench.py's 0.4 s: the workload is not stationary -- later cycles cost more
+#  instructions -- and a time span makes the set of profiled launches depend on the box and on the pass; earlier rounds' passes
+#  saw 330...400 pre-roll cycles on the headline, which is why 384: cycles 0...383, then 0...49 again)
+B="--steps 40 --warmup 10 --clock-warmup-cycles 384 --no-cpu-baseline --no-parity --no-extra-regions"
 cfg() {  # name, bench args
   name=$1; shift
   for pass in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \

@@ -4,17 +4,18 @@
 // (`Eigen::Matrix<double, DIM, 1>` in src/Measurement.hpp:9-10 and src/UnscentedKalmanFilter.hpp:142-147,
 // `filter_state_cov.block(0, 0, 3, 3) = ...; filter_state_cov.setZero();` in
 // src/pose_with_velocity/BodyStateMeasurement.hpp:21-25,35-38, `MTK::SO3<double>(q)` in :17).  Where Eigen is
-// installed these types ARE Eigen's (`__has_include(<Eigen/Core>)`); in an image without Eigen (this one) the
-// dependency-free stand-ins below offer the members that code uses, with Eigen's names and semantics, so the
-// same caller text compiles either way.  They carry values only; all filter arithmetic happens in the HIP kernels
+// installed these types CAN BE Eigen's (opt in: -DPOSE_ESTIMATION_USE_EIGEN, see below); by default, and in an image
+// without Eigen (this one), the dependency-free stand-ins below offer the members that code uses, with Eigen's names
+// and semantics, so the same caller text compiles either way.  They carry values only; all filter arithmetic happens in the HIP kernels
 // behind include/ukf_batch.h.  The stand-in stores row-major, Eigen column-major: matrices therefore cross the C-ABI
 // (row-major, lower triangle read -- as Eigen's LLT reads the reference's sigma_) through the explicit (row, column)
 // loops of to_row_major / from_row_major below, never through data().
 //
-// THE REAL-EIGEN BRANCH HAS NEVER BEEN COMPILED in the build image (Eigen is absent there): it is untested.  Two
-// differences to expect: a default-constructed Eigen matrix is uninitialised where the stand-in zero-fills, and Eigen's
-// expression templates may need .eval() where the stand-in returns values.  -DPOSE_ESTIMATION_NO_EIGEN keeps the
-// stand-ins even where Eigen is installed.
+// THE REAL-EIGEN BRANCH HAS NEVER BEEN COMPILED in the build image (Eigen is absent there): it is untested, and therefore
+// not the default -- the stand-ins are what every test of this repository has run.  -DPOSE_ESTIMATION_USE_EIGEN selects it
+// where Eigen is installed.  Two differences to expect: a default-constructed Eigen matrix is
+// uninitialised where the stand-in zero-fills, and Eigen's expression templates may need .eval() where the stand-in
+// returns values.  (-DPOSE_ESTIMATION_NO_EIGEN, the switch of earlier rounds, still forces the stand-ins.)
 #ifndef POSE_ESTIMATION_TYPES_HPP
 #define POSE_ESTIMATION_TYPES_HPP
 
@@ -22,7 +23,7 @@
 #include <cstddef>
 
 #if defined(__has_include)
-#if __has_include(<Eigen/Core>) && __has_include(<Eigen/Geometry>) && !defined(POSE_ESTIMATION_NO_EIGEN)
+#if defined(POSE_ESTIMATION_USE_EIGEN) && __has_include(<Eigen/Core>) && __has_include(<Eigen/Geometry>) && !defined(POSE_ESTIMATION_NO_EIGEN)
 #define POSE_ESTIMATION_HAS_EIGEN 1
 #endif
 #endif

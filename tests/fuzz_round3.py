@@ -48,9 +48,12 @@ def bucket_scenario(rng, k):
     m_t = torch.from_numpy(models).cuda()
     torch.cuda.synchronize()
     dt = float(rng.choice([0.005, 0.01, 0.05]))
+    # (a third of the fp32 scenarios in the wide-arithmetic mode -- fp32 arrays, fp64 arithmetic; drawn from a stream of its own so
+    #  that the scenarios of a seed are what they were before the mode existed)
+    wide = {"wide_arithmetic": 1} if (prec == 1 and np.random.default_rng([k, 77]).random() < 0.34) else {}
     out = []
     for b in (1, 0):
-        e = spe.BatchPoseUKF(n, precision=prec, bucket_models=b)
+        e = spe.BatchPoseUKF(n, precision=prec, bucket_models=b, **wide)
         e.initialize(mu, cov)
         e.set_acceleration(None, 0.01 * np.eye(3))
         if use_acc:
